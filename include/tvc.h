@@ -1,0 +1,259 @@
+/*
+ * tvc.h -- C ABI of the MI355X-native text-variant-consistency (TVC) hot path.
+ *
+ * The reference (Zhang-Xin-Duke/multimodal-detection-consistency) is pure
+ * Python and has no FFI; its boundary for this path is duck-typed Python
+ * (SURVEY.md section 8b).  This header is the C-ABI that sits underneath the
+ * Python mirror in multimodal-detection-consistency_amd/: plain pointers and
+ * sizes, no torch types.  Each entry point names the reference call sites it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer owned by the caller
+ *     (in practice a PyTorch-ROCm tensor's data_ptr());
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *     the call never synchronises the device (exceptions are documented);
+ *   - return value 0 = TVC_OK, otherwise an error code; the message is
+ *     available from tvc_last_error();
+ *   - a handle belongs to one GPU and is not thread-safe (the Python shim
+ *     holds a lock around submission);
+ *   - bf16 buffers are raw uint16_t bit patterns (round-to-nearest-even).
+ */
+#ifndef TVC_H_
+#define TVC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVC_ABI_VERSION 1
+
+enum {
+    TVC_OK = 0,
+    TVC_E_INVALID = 1,     /* bad argument / unsupported geometry            */
+    TVC_E_HIP = 2,         /* a HIP runtime call failed                      */
+    TVC_E_NOMEM = 3,       /* workspace allocation failed                    */
+    TVC_E_STATE = 4,       /* e.g. bank search before tvc_bank_set           */
+    TVC_E_OVERFLOW = 5     /* candidate lists overflowed (see tvc_bank_status) */
+};
+
+enum { TVC_DTYPE_BF16 = 0, TVC_DTYPE_F32 = 1 };
+
+typedef struct tvc_handle tvc_handle;
+
+/* Transformer tower geometry (OpenAI-CLIP style, pre-LN, quick-GELU). */
+typedef struct {
+    int32_t width;    /* d_model                          */
+    int32_t layers;
+    int32_t heads;    /* head_dim = width / heads, must be 64 */
+    int32_t mlp;      /* hidden size of the MLP           */
+} tvc_tower_arch;
+
+typedef struct {
+    int32_t image_size;   /* 224                                  */
+    int32_t patch;        /* 32 (ViT-B/32), 14 (ViT-L/14)         */
+    int32_t vocab;        /* 49408                                */
+    int32_t ctx;          /* 77                                   */
+    int32_t embed_dim;    /* D: 512 (B/32), 768 (L/14)            */
+    tvc_tower_arch vision;
+    tvc_tower_arch text;
+} tvc_model_desc;
+
+/* One residual attention block.  GEMM weights are bf16 [out, in] row-major
+ * (the nn.Linear layout); LayerNorm parameters and biases are fp32. */
+typedef struct {
+    const float*    ln1_g;  const float* ln1_b;
+    const uint16_t* wqkv;   /* [3d, d]  rows: q | k | v            */
+    const float*    bqkv;   /* [3d]                                 */
+    const uint16_t* wo;     /* [d, d]                               */
+    const float*    bo;
+    const float*    ln2_g;  const float* ln2_b;
+    const uint16_t* w1;     /* [mlp, d]                             */
+    const float*    b1;
+    const uint16_t* w2;     /* [d, mlp]                             */
+    const float*    b2;
+} tvc_layer_weights;
+
+typedef struct {
+    const uint16_t* patch_w;   /* bf16 [d, Kp], Kp = round_up(3*patch*patch, 64), zero padded;
+                                  columns ordered (c, ky, kx) like the conv weight          */
+    const float* cls;          /* [d]                                                       */
+    const float* pos;          /* [T, d], T = (image_size/patch)^2 + 1                      */
+    const float* ln_pre_g;  const float* ln_pre_b;
+    const float* ln_post_g; const float* ln_post_b;
+    const uint16_t* proj;      /* bf16 [D, d]                                               */
+    const tvc_layer_weights* layers;   /* HOST array of `vision.layers` structs            */
+} tvc_vision_weights;
+
+typedef struct {
+    const float* tok_emb;      /* fp32 [vocab, d]                                           */
+    const float* pos;          /* fp32 [ctx, d]                                             */
+    const float* ln_final_g; const float* ln_final_b;
+    const uint16_t* proj;      /* bf16 [D, d]                                               */
+    const tvc_layer_weights* layers;   /* HOST array of `text.layers` structs              */
+} tvc_text_weights;
+
+/* ---- lifetime -------------------------------------------------------- */
+
+uint32_t tvc_abi_version(void);
+
+/* Create a handle on the current HIP device.  `vision`/`text` may be NULL
+ * (no tower of that kind: tvc_encode_* then fails with TVC_E_STATE; `desc`
+ * may be NULL when both are).  The weight buffers are referenced, not copied:
+ * the caller keeps them alive.
+ * Replaces: constructing the (absent) src.models CLIPModel(CLIPConfig(...))
+ * -- src/detector.py:258-271, src/retrieval.py:356-361. */
+int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision,
+               const tvc_text_weights* text, tvc_handle** out);
+void tvc_destroy(tvc_handle* h);
+
+/* Message of the last error on `h` (or of the last failed tvc_create when
+ * h == NULL).  Never NULL. */
+const char* tvc_last_error(tvc_handle* h);
+
+/* Bytes of device workspace currently held by the handle. */
+uint64_t tvc_workspace_bytes(tvc_handle* h);
+
+/* ---- encoders (K1, K2, K3 of SURVEY.md 2.3) -------------------------- */
+
+/* pix_dev: fp32 [B, 3, image_size, image_size] (already preprocessed);
+ * out_dev: fp32 [B, D], L2-normalised when `normalize` != 0.
+ * Replaces clip_model.encode_image / encode_image_tensor(x, requires_grad=False):
+ * src/detector.py:626,633; experiments/defenses/detector.py:238;
+ * src/retrieval.py:407,609. */
+int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B,
+                     float* out_dev, int32_t normalize, void* stream);
+
+/* tok_dev: int32 [T, ctx] CLIP BPE ids (SOT ... EOT, 0-padded); pooled at the
+ * arg-max id (the EOT token).  out_dev: fp32 [T, D].
+ * Replaces clip_model.encode_text: experiments/defenses/detector.py:239,247;
+ * experiments/defenses/retrieval_ref.py:238-244; src/retrieval.py:451,551. */
+int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t T,
+                    float* out_dev, int32_t normalize, void* stream);
+
+/* ---- reference bank (K5) --------------------------------------------- */
+
+/* Register the bank: dense row-major [R, D], rows L2-normalised
+ * (scripts/build_faiss_indices.py:108-109,138; retrieval_ref.py:99,156).
+ * dtype TVC_DTYPE_BF16: used in place (caller keeps it alive).
+ * dtype TVC_DTYPE_F32: split once into bf16 (hi, lo) planes inside the handle
+ * (3-product split-bf16 GEMM, fp32-grade cosines).
+ * Replaces faiss.IndexFlatIP(d).add(features): src/retrieval.py:225-226,
+ * retrieval_ref.py:140,156. */
+int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D,
+                 int32_t dtype, void* stream);
+
+/* Exact top-k inner-product search of M query rows against the bank, fused
+ * with per-row moments; the [M, R] matrix is never materialised.
+ *   rows_dev   fp32 [M, D] (L2-normalised by the caller when cosines are wanted)
+ *   k          1..32
+ *   topk_idx   int32 [M, k]  global row index (local + idx_offset), -1 = none
+ *   topk_sim   fp32  [M, k]  descending; ties broken by ascending index
+ *   moments    fp32  [M, 4]  sum, sum of squares, max, count(sim >= count_thr)
+ *                            over ALL R rows (may be NULL)
+ * Replaces index.search(q, k) / np.dot + argpartition + argsort:
+ * src/retrieval.py:636-673, retrieval_ref.py:246-290, src/ref_bank.py:475-484.
+ * Returns TVC_OK after enqueueing; overflow of the internal candidate lists is
+ * reported by tvc_bank_status() after the stream has been synchronised. */
+int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k,
+                    float count_thr, int64_t idx_offset,
+                    int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
+                    void* stream);
+
+/* Synchronises `stream` and returns TVC_E_OVERFLOW if the last
+ * tvc_bank_search dropped candidates (degenerate banks, e.g. thousands of
+ * identical rows); TVC_OK otherwise. */
+int tvc_bank_status(tvc_handle* h, void* stream);
+
+/* out_dev fp32 [n, D]: bank rows for LOCAL indices idx_dev[n] (global index -
+ * idx_offset); rows with idx < 0 or >= R are zero-filled.
+ * Replaces self.reference_features[idx] (retrieval_ref.py:262,286). */
+int tvc_bank_gather(tvc_handle* h, const int32_t* idx_dev, int32_t n,
+                    int64_t idx_offset, float* out_dev, void* stream);
+
+/* Merge W per-shard partial results (the RCCL all-gather / all-to-all output)
+ * into the global top-k: parts are [W, M, k] (idx, sim) each sorted descending,
+ * feat_parts fp32 [W, M, kf, D] or NULL carries the rows of the first kf
+ * entries of every part; outputs as tvc_bank_search plus feat_out [M, kf, D].
+ * mom_parts [W, M, 4] / mom_out [M, 4] may be NULL.
+ * Replaces dist.all_gather + host merge (src/utils/multi_gpu_processor.py:595-612). */
+int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim_parts_dev,
+                   const float* feat_parts_dev, const float* mom_parts_dev,
+                   int32_t W, int32_t M, int32_t k, int32_t kf, int32_t D,
+                   int32_t* idx_out_dev, float* sim_out_dev, float* feat_out_dev,
+                   float* mom_out_dev, void* stream);
+
+/* All-pairs cosine matrix out[n, m] = cos(x[n], y[m]), fp32-grade (both sides
+ * L2-normalised on device, split into bf16 (hi, lo) planes, three MFMA products).
+ * x fp32 [N, D], y fp32 [M, D], out fp32 [N, M]; D % 64 == 0.
+ * Replaces sklearn cosine_similarity / F.normalize + mm:
+ * src/retrieval.py:706 (compute_similarity_matrix), src/utils/metrics.py:144-164. */
+int tvc_cosine_matrix(tvc_handle* h, const float* x_dev, int32_t N, const float* y_dev, int32_t M,
+                      int32_t D, float* out_dev, void* stream);
+
+/* ---- per-query consistency (K4, K6, K7) ------------------------------ */
+
+typedef struct {
+    int32_t reference_count;      /* refs kept per text row, retrieval_ref.py:23 (5)   */
+    float   similarity_threshold; /* retrieval_ref.py:24 (0.3)                         */
+    int32_t retrieval_top_k;      /* experiments/defenses/detector.py:29 (10), <= 16   */
+    float   dup_threshold;        /* experiments/defenses/detector.py:318 (0.95)       */
+    float   w_text_variants;      /* src/detector.py:667 (0.4)                         */
+    float   w_consistency;        /* src/detector.py:669 (0.2)                         */
+    float   w_exp[4];             /* consistency_checker.py:61-66 (0.25 each): original,
+                                     text_variant, retrieval, generative               */
+} tvc_consistency_params;
+
+/* Record layout, fp32 words per query (tvc_consistency writes rec_stride words):
+ *  [0] original_similarity s0      [1] mean(sv)       [2] std(sv) (ddof 0)
+ *  [3] text-variant score  (src/detector.py:479-485)
+ *  [4] consistency score 1-s0 (src/detector.py:579)
+ *  [5] aggregated src score (weighted_mean over the two, src/detector.py:664-680)
+ *  [6] retrieval_consistency  [7] retrieval_std  [8] number of refs kept
+ *  [9] cross_modal_variance (experiments/defenses/detector.py:295-300)
+ * [10] overall score, weighted voting (consistency_checker.py:147-160)
+ * [11] reserved
+ * [12 .. 12+N)        sv[n]
+ * [12+N .. +16)       kept reference indices (int32 bit patterns, -1 padded)
+ * [12+N+16 .. +16)    cos(image, kept reference) */
+#define TVC_REC_HEAD 12
+#define TVC_REC_MAXREF 16
+static inline int32_t tvc_rec_stride(int32_t N) { return TVC_REC_HEAD + N + 2 * TVC_REC_MAXREF; }
+
+/* img_dev fp32 [B, D]; txt_dev fp32 [B, N+1, D] (row 0 = original text);
+ * ref_idx/ref_sim [B*(N+1), ks] = bank search results of the text rows
+ * (global indices), ref_feat fp32 [B*(N+1), kf, D] = rows of the first kf
+ * (>= reference_count) results; pass ks = 0 / NULLs for "no bank".
+ * rec_dev fp32 [B, tvc_rec_stride(N)].
+ * Replaces src/detector.py:461-485,573-579,643-682 and
+ * experiments/defenses/detector.py:184-204,228-300,302-325. */
+int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev,
+                    int32_t B, int32_t N, int32_t D,
+                    const int32_t* ref_idx_dev, const float* ref_sim_dev,
+                    const float* ref_feat_dev, int32_t ks, int32_t kf,
+                    const tvc_consistency_params* params, float* rec_dev, void* stream);
+
+/* ---- building blocks exported for parity tests and profiling --------- */
+
+/* out[j, i] = sum_k a[i, k] * b[j, k]  (+ bias[i]); a bf16 [I, K] ("weights"),
+ * b bf16 [J, K] ("tokens"); K % 64 == 0.  epilogue: 0 = fp32 store,
+ * 1 = bf16 store, 2 = bf16 quick-GELU, 3 = fp32 residual add (out += ...). */
+int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev,
+                  const float* bias_dev, void* out_dev, int32_t I, int32_t J, int32_t K,
+                  int32_t ld_out, int32_t epilogue, void* stream);
+
+/* Multi-head attention over packed sequences: qkv bf16 [rows, 3*width]
+ * (q | k | v), sequences of `seq_len` consecutive rows, out bf16 [rows, width]. */
+int tvc_attention(tvc_handle* h, const uint16_t* qkv_dev, uint16_t* out_dev,
+                  int32_t n_seq, int32_t seq_len, int32_t heads, int32_t causal, void* stream);
+
+/* y bf16 [rows, d] = LayerNorm(x fp32 [rows, d]) * g + b, eps 1e-5. */
+int tvc_layernorm(tvc_handle* h, const float* x_dev, const float* g_dev, const float* b_dev,
+                  uint16_t* y_dev, int32_t rows, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVC_H_ */

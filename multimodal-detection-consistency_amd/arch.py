@@ -1,0 +1,72 @@
+"""CLIP geometries the hot path supports (OpenAI-CLIP layouts).
+
+The reference selects the model by name through ``CLIPConfig(model_name=...)``
+(``src/retrieval.py:356-361``; ``"ViT-B/32"`` default, ``"ViT-L/14"`` supported,
+``src/__init__.py:99-108``).  ``"ViT-T/16-test"`` is a tiny geometry used only
+by the test-suite and ``smoke()``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Tower:
+    width: int
+    layers: int
+    heads: int
+    mlp: int
+
+
+@dataclass(frozen=True)
+class ClipArch:
+    name: str
+    image_size: int
+    patch: int
+    vision: Tower
+    text: Tower
+    embed_dim: int
+    vocab: int = 49408
+    ctx: int = 77
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image_size // self.patch) ** 2
+
+    @property
+    def vision_tokens(self) -> int:
+        return self.n_patches + 1
+
+    @property
+    def patch_k(self) -> int:
+        return 3 * self.patch * self.patch
+
+    @property
+    def patch_k_padded(self) -> int:
+        return (self.patch_k + 63) // 64 * 64
+
+    def flops_image(self) -> float:
+        """Forward FLOPs (2 x MACs) of the vision tower for one image."""
+        v, T = self.vision, self.vision_tokens
+        per_layer = 2 * T * v.width * (3 * v.width + v.width + 2 * v.mlp) + 4 * T * T * v.width
+        return 2 * self.n_patches * self.patch_k * v.width + v.layers * per_layer + 2 * v.width * self.embed_dim
+
+    def flops_text(self) -> float:
+        t, T = self.text, self.ctx
+        per_layer = 2 * T * t.width * (3 * t.width + t.width + 2 * t.mlp) + 4 * T * T * t.width
+        return t.layers * per_layer + 2 * t.width * self.embed_dim
+
+
+ARCHS = {
+    "ViT-B/32": ClipArch("ViT-B/32", 224, 32, Tower(768, 12, 12, 3072), Tower(512, 12, 8, 2048), 512),
+    "ViT-L/14": ClipArch("ViT-L/14", 224, 14, Tower(1024, 24, 16, 4096), Tower(768, 12, 12, 3072), 768),
+    "ViT-T/16-test": ClipArch("ViT-T/16-test", 64, 16, Tower(256, 2, 4, 512), Tower(128, 2, 2, 256), 128,
+                              vocab=49408, ctx=77),
+}
+
+
+def get_arch(name: str) -> ClipArch:
+    try:
+        return ARCHS[name]
+    except KeyError:
+        raise ValueError(f"unknown CLIP geometry {name!r}; supported: {sorted(ARCHS)}") from None

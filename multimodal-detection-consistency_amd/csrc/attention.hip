@@ -1,0 +1,191 @@
+// Multi-head self-attention for the CLIP towers (head_dim 64, T <= 288).
+//
+// One workgroup (4 waves) per (sequence, head).  The head's K and V live in
+// LDS for the whole workgroup (T <= 288 rows x 64), so the softmax is exact
+// and single-pass: no online rescale.  Each wave walks 16-query blocks:
+//
+//   S^T[key, q]  = K . Q^T      MFMA 16x16x32, A = K rows from LDS (ds_read_b128,
+//                               XOR-swizzled 128-B rows), B = Q straight from HBM
+//   softmax over keys           lane-local over the accumulator registers, then
+//                               two xor-shuffles across the 4 lane groups
+//   O^T[dh, q]   = V^T . P^T    A = V^T via ds_read_b64_tr_b16 (hardware
+//                               transpose of the row-major V image), B = P^T packed
+//                               from the S^T accumulators with NO lane movement
+//                               (k-slot order chosen to match the accumulator map)
+//
+// "Swapped" products keep the query on the lane (column) dimension, so row
+// statistics are per-lane scalars and the output is 8-byte row pieces.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define ATT_DH 64
+#define ATT_KROW 128     // K image: 64 bf16 per row
+#define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
+
+template <int MAXT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv,
+                                                        uint16_t* __restrict__ out, int T, int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int width = heads * ATT_DH;
+    const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+    const int64_t row0 = (int64_t)seq * T;
+    const int NT = (T + 15) >> 4;          // key tiles of 16
+    const int NP = (NT + 1) >> 1;          // key pairs of 32
+    const int KT = NT * 16, VT = NP * 32;
+    char* ldsK = smem;
+    char* ldsV = smem + KT * ATT_KROW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t ld = 3 * (int64_t)width;
+
+    // ---- fill K / V images (zero beyond T) --------------------------------
+    for (int idx = tid; idx < KT * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + width + h * ATT_DH + c * 8);
+        *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+    }
+    for (int idx = tid; idx < VT * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + 2 * width + h * ATT_DH + c * 8);
+        *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = v;
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, r16 = lane & 15;
+    const int sw0 = ((0 + g) ^ ((lane >> 1) & 7)) << 4;
+    const int sw1 = ((4 + g) ^ ((lane >> 1) & 7)) << 4;
+    // transposed-read lane address: lane i of a 16-lane group supplies row (i>>2),
+    // columns 4*(i&3) .. +3 of a [4 keys][16 dh] block
+    const int tr_off = (4 * g + (r16 >> 2)) * ATT_VROW + ((r16 & 3) << 3);
+    const float scale_log2 = 0.125f * 1.4426950408889634f;   // dh^-0.5 * log2(e)
+    const int NQ = NT;
+
+    for (int qb = wave; qb < NQ; qb += 4) {
+        const int qr = qb * 16 + r16;
+        const int qrc = qr < T ? qr : T - 1;
+        const uint16_t* qp = qkv + (row0 + qrc) * ld + h * ATT_DH + 8 * g;
+        const bf16x8_t bq0 = *(const bf16x8_t*)(qp);
+        const bf16x8_t bq1 = *(const bf16x8_t*)(qp + 32);
+        const int nt_q = CAUSAL ? ((qb + 1 < NT) ? qb + 1 : NT) : NT;
+
+        f32x4_t s[MAXT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (t < nt_q) {
+                const char* kr = ldsK + (t * 16 + r16) * ATT_KROW;
+                const bf16x8_t a0 = *(const bf16x8_t*)(kr + sw0);
+                const bf16x8_t a1 = *(const bf16x8_t*)(kr + sw1);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
+                const bool need_mask = (t * 16 + 16 > T) || (CAUSAL && t == qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[t][r] * scale_log2;
+                    if (need_mask) {
+                        const int key = t * 16 + 4 * g + r;
+                        if (key >= T || (CAUSAL && key > qr)) v = -INFINITY;
+                    }
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+
+        float lsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < nt_q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[t][r] - mx);
+                    s[t][r] = p;
+                    lsum += p;
+                }
+            }
+        }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+
+        f32x4_t o[4];
+#pragma unroll
+        for (int md = 0; md < 4; ++md) o[md] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < (MAXT + 1) / 2; ++u) {
+            const int t0 = 2 * u, t1 = 2 * u + 1;
+            if (t0 < nt_q) {
+                // k-slots j<4: keys 16*t0 + 4g + j ; j>=4: keys 16*t1 + 4g + (j-4)
+                const f32x4_t p0 = s[t0];
+                const f32x4_t p1 = (t1 < MAXT) ? s[t1 < MAXT ? t1 : 0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                u32x4_t pk;
+                pk[0] = pack_bf16x2(p0[0], p0[1]);
+                pk[1] = pack_bf16x2(p0[2], p0[3]);
+                pk[2] = pack_bf16x2(p1[0], p1[1]);
+                pk[3] = pack_bf16x2(p1[2], p1[3]);
+                const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pk);
+#pragma unroll
+                for (int md = 0; md < 4; ++md) {
+                    const char* vb = ldsV + tr_off + md * 32;
+                    const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(vb + t0 * 16 * ATT_VROW));
+                    const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(vb + t1 * 16 * ATT_VROW));
+                    bf16x8_t a;
+                    a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3];
+                    a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
+                    o[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, o[md], 0, 0, 0);
+                }
+            }
+        }
+        if (qr < T) {
+            const float inv = 1.0f / lsum;
+            uint16_t* op = out + (row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;
+#pragma unroll
+            for (int md = 0; md < 4; ++md) {
+                u32x2_t w;
+                w[0] = pack_bf16x2(o[md][0] * inv, o[md][1] * inv);
+                w[1] = pack_bf16x2(o[md][2] * inv, o[md][3] * inv);
+                *(u32x2_t*)(op + md * 16) = w;
+            }
+        }
+    }
+}
+
+template <int MAXT, bool CAUSAL>
+static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, int n_seq, int T, int heads,
+                             hipStream_t stream) {
+    const int NT = (T + 15) / 16, NP = (NT + 1) / 2;
+    const size_t lds = (size_t)NT * 16 * ATT_KROW + (size_t)NP * 32 * ATT_VROW;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (st != hipSuccess) return st;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL>), dim3(n_seq * heads), dim3(256), lds, stream,
+                       qkv, out, T, heads);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, int n_seq, int seq_len, int heads,
+                            int causal, hipStream_t stream) {
+    if (n_seq <= 0) return hipSuccess;
+    if (seq_len < 1 || seq_len > 288 || heads < 1) return hipErrorInvalidValue;
+    const int NT = (seq_len + 15) / 16;
+    if (causal) {
+        if (NT <= 2) return launch_one<2, true>(qkv, out, n_seq, seq_len, heads, stream);
+        if (NT <= 6) return launch_one<6, true>(qkv, out, n_seq, seq_len, heads, stream);
+        return launch_one<18, true>(qkv, out, n_seq, seq_len, heads, stream);
+    }
+    if (NT <= 2) return launch_one<2, false>(qkv, out, n_seq, seq_len, heads, stream);
+    if (NT <= 4) return launch_one<4, false>(qkv, out, n_seq, seq_len, heads, stream);
+    if (NT <= 6) return launch_one<6, false>(qkv, out, n_seq, seq_len, heads, stream);
+    return launch_one<18, false>(qkv, out, n_seq, seq_len, heads, stream);
+}

@@ -1,0 +1,456 @@
+// K5: exact top-k inner-product search of query rows against the reference
+// bank, fused with per-row moments.  The [M, R] similarity matrix is never
+// written: it lives only in MFMA accumulators.
+//
+//   pass 0  a strided SAMPLE of the bank (n_sample rows) is multiplied with the
+//           query planes by the dense GEMM (fp32 store) and `kth_bound` turns
+//           each query's sample row into tau[q] = a LOWER bound of its final
+//           k-th best similarity (the k-th largest of 256 disjoint group
+//           maxima: k distinct sample elements are >= it).
+//   pass 1  `bank_search_kernel`: persistent workgroups own (query tile, bank
+//           chunk); per 256x256 tile they run the GEMM main loop (bank rows on
+//           the MFMA row dimension, queries on the lane dimension, so every
+//           lane filters against its OWN query's tau), accumulate sum / sumsq /
+//           max / count in registers and append the few survivors (v > tau) to
+//           a per-(chunk, query) list: slot from an LDS counter, no global
+//           atomics.
+//   pass 2  `bank_select_kernel`: one workgroup per query gathers its lists
+//           (~1-2k entries) into LDS and extracts the k best, ordered by
+//           (similarity desc, index asc); reduces the moments over chunks.
+//
+// Precision: queries are split into bf16 (hi, lo) planes, so with a bf16 bank
+// the products are exact and the result is the fp32-accumulated cosine of the
+// stored values (|err| ~ 1e-6); an fp32 bank is split the same way and uses the
+// three products hi.hi + lo.hi + hi.lo.
+#include "gemm_core.hpp"
+#include "kernels.hpp"
+
+#define BANK_CAP 64
+#define BANK_POOL 6144
+#define BANK_LDS_BYTES (GEMM_LDS_BYTES + 256 * 4 + 2 * 256 * 4 * 4)
+
+struct Cand {
+    float v;
+    int32_t idx;
+};
+
+void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap) {
+    const int64_t nbt = (R + GEMM_BM - 1) / GEMM_BM;
+    const int nqt = (M + GEMM_BN - 1) / GEMM_BN;
+    int64_t s = (1280 + nqt - 1) / nqt;
+    if (s > nbt) s = nbt;
+    if (s < 1) s = 1;
+    const int64_t tpc = (nbt + s - 1) / s;
+    s = (nbt + tpc - 1) / tpc;
+    // expected survivors per query ~ k * R / n_sample: aim at 16 per chunk list
+    // (cap 64) and at most ~2048 per query (select pool 6144)
+    int64_t ns = (int64_t)k * R / (16 * s);
+    const int64_t ns2 = (int64_t)k * R / 2048;
+    if (ns < ns2) ns = ns2;
+    if (ns < 4096) ns = 4096;
+    if (ns > 65536) ns = 65536;
+    ns = (ns + 255) / 256 * 256;
+    if (ns > R) ns = R;
+    if (ns < 1) ns = 1;
+    *n_sample = (int)ns;
+    *sample_stride = (int)(R / ns > 0 ? R / ns : 1);
+    *S = (int)s;
+    *cap = BANK_CAP;
+}
+
+// tau[q] = (k-th largest of 256 group maxima of s0[q, :]) minus a safety margin
+__global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict__ s0, int n_sample,
+                                                        int k, float* __restrict__ tau) {
+    __shared__ float gm[256];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const float* row = s0 + (int64_t)q * n_sample;
+    float m = -INFINITY;
+    for (int i = t; i < n_sample; i += 256) m = fmaxf(m, row[i]);
+    gm[t] = m;
+    __syncthreads();
+    int rank = 0;
+    for (int u = 0; u < 256; ++u) {
+        const float o = gm[u];
+        rank += (o > m) || (o == m && u < t);
+    }
+    if (rank == k - 1) {
+        float v = m;
+        if (v > -INFINITY) v = v - 1e-6f - 1e-6f * fabsf(v);
+        tau[q] = v;
+    }
+}
+
+struct BankEpilogue {
+    const float* tau;      // [M]
+    Cand* cand;            // [S, M, cap]
+    int32_t* cand_cnt;     // [S, M]
+    float* mom_part;       // [S, M, 4]
+    int32_t* overflow;
+    int64_t R;
+    int64_t idx_offset;
+    int M;
+    float count_thr;
+};
+
+template <bool FULL>
+__device__ __forceinline__ void bank_tile_epilogue(const gemm_acc_t& acc, const BankEpilogue& e,
+                                                   int64_t tile_row0, int chunk, int j0, int wm, int wn,
+                                                   int lane, const float (&tau)[4], float (&sum)[4],
+                                                   float (&sq)[4], float (&mx)[4], float (&cn)[4],
+                                                   int* lds_cnt) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int ql = wn * 64 + n * 16 + (lane & 15);
+        const int q = j0 + ql;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int64_t row = tile_row0 + wm * 128 + m * 16 + (lane >> 4) * 4;
+            f32x4_t v = acc[m][n];
+            if (!FULL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row + r >= e.R) v[r] = -INFINITY;
+            }
+            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (FULL) {
+                sum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                sq[n] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], sq[n]))));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row + r < e.R) { sum[n] += v[r]; sq[n] = fmaf(v[r], v[r], sq[n]); }
+            }
+            mx[n] = fmaxf(mx[n], m4);
+            if (m4 >= e.count_thr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cn[n] += (v[r] >= e.count_thr) ? 1.f : 0.f;
+            }
+            if (m4 > tau[n]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (v[r] > tau[n]) {
+                        // rare path (a few survivors per lane per bank chunk): keep
+                        // its address arithmetic inside the branch, not hoisted into
+                        // registers that stay live across the main loop
+                        int qlo = ql;
+                        asm volatile("" : "+v"(qlo));
+                        const int slot = atomicAdd(&lds_cnt[qlo], 1);
+                        if (slot < BANK_CAP) {
+                            Cand c;
+                            c.v = v[r];
+                            c.idx = (int32_t)(row + r + e.idx_offset);
+                            e.cand[((int64_t)chunk * e.M + (j0 + qlo)) * BANK_CAP + slot] = c;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS) void bank_search_kernel(GemmOperands g, BankEpilogue e,
+                                                                   int nQt, int S, int tiles_per_chunk,
+                                                                   int n_bank_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds_cnt = (int*)(smem + GEMM_LDS_BYTES);
+    float* lds_mom = (float*)(smem + GEMM_LDS_BYTES + 256 * 4);
+    // query tile slowest: an XCD owns ~2-3 query tiles (their planes stay in its
+    // L2) and streams the whole bank
+    const int lin = xcd_contiguous(blockIdx.x, nQt * S);
+    const int qt = lin / S, chunk = lin - qt * S;
+    const int j0 = qt * GEMM_BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    if (threadIdx.x < 256) lds_cnt[threadIdx.x] = 0;
+    float tau[4], sum[4], sq[4], mx[4], cn[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int q = j0 + wn * 64 + n * 16 + (lane & 15);
+        tau[n] = (q < e.M) ? e.tau[q] : INFINITY;
+        sum[n] = 0.f; sq[n] = 0.f; mx[n] = -INFINITY; cn[n] = 0.f;
+    }
+    __syncthreads();
+
+    const int bt0 = chunk * tiles_per_chunk;
+    int bt1 = bt0 + tiles_per_chunk;
+    if (bt1 > n_bank_tiles) bt1 = n_bank_tiles;
+    for (int bt = bt0; bt < bt1; ++bt) {
+        gemm_acc_t acc;
+        gemm_zero_acc(acc);
+        const int64_t tile_row0 = (int64_t)bt * GEMM_BM;
+        gemm_mainloop(acc, g, (int)tile_row0, j0, smem);
+        if (tile_row0 + GEMM_BM <= e.R)
+            bank_tile_epilogue<true>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
+        else
+            bank_tile_epilogue<false>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
+    }
+
+    // moments: the 4 lane groups of a wave and the 2 wm-waves share a query
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        float s = sum[n], s2 = sq[n], m = mx[n], c = cn[n];
+        s += __shfl_xor(s, 16, 64);  s += __shfl_xor(s, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        c += __shfl_xor(c, 16, 64);  c += __shfl_xor(c, 32, 64);
+        m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if ((lane >> 4) == 0) {
+            float* p = lds_mom + ((wm * 256) + wn * 64 + n * 16 + (lane & 15)) * 4;
+            p[0] = s; p[1] = s2; p[2] = m; p[3] = c;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int q = j0 + threadIdx.x;
+        if (q < e.M) {
+            const float* a = lds_mom + threadIdx.x * 4;
+            const float* b = lds_mom + (256 + threadIdx.x) * 4;
+            float* o = e.mom_part + ((int64_t)chunk * e.M + q) * 4;
+            o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = fmaxf(a[2], b[2]); o[3] = a[3] + b[3];
+            int c = lds_cnt[threadIdx.x];
+            if (c > BANK_CAP) { c = BANK_CAP; atomicOr(e.overflow, 1); }
+            e.cand_cnt[(int64_t)chunk * e.M + q] = c;
+        }
+    }
+}
+
+// (v desc, idx asc) ordering
+__device__ __forceinline__ bool cand_better(float v, int idx, float ov, int oidx) {
+    return (v > ov) || (v == ov && idx < oidx);
+}
+
+__global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict__ cand,
+                                                          const int32_t* __restrict__ cand_cnt,
+                                                          const float* __restrict__ mom_part, int S, int M,
+                                                          int k, int32_t* __restrict__ topk_idx,
+                                                          float* __restrict__ topk_sim,
+                                                          float* __restrict__ moments,
+                                                          int32_t* __restrict__ overflow) {
+    __shared__ Cand pool[BANK_POOL];
+    __shared__ int scan[256];
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ int red_p[4];
+    __shared__ float mom_red[4][4];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+
+    // chunks handled by this thread: c = t, t+256, ...
+    int mine = 0;
+    for (int c = t; c < S; c += 256) mine += cand_cnt[(int64_t)c * M + q];
+    scan[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (t >= o) ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const int total_all = scan[255];
+    int off = scan[t] - mine;
+    for (int c = t; c < S; c += 256) {
+        const int n = cand_cnt[(int64_t)c * M + q];
+        const Cand* src = cand + ((int64_t)c * M + q) * BANK_CAP;
+        for (int i = 0; i < n; ++i) {
+            if (off < BANK_POOL) pool[off] = src[i];
+            ++off;
+        }
+    }
+    if (t == 0 && total_all > BANK_POOL) atomicOr(overflow, 2);
+    const int total = total_all < BANK_POOL ? total_all : BANK_POOL;
+    __syncthreads();
+
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, bp = -1;
+        for (int i = t; i < total; i += 256) {
+            const Cand c = pool[i];
+            if (c.idx >= 0 && cand_better(c.v, c.idx, bv, bi)) { bv = c.v; bi = c.idx; bp = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const int op = __shfl_xor(bp, o, 64);
+            if (op >= 0 && (bp < 0 || cand_better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; red_p[wave] = bp; }
+        __syncthreads();
+        if (t == 0) {
+            float fv = red_v[0]; int fi = red_i[0], fp = red_p[0];
+            for (int w = 1; w < 4; ++w)
+                if (red_p[w] >= 0 && (fp < 0 || cand_better(red_v[w], red_i[w], fv, fi))) {
+                    fv = red_v[w]; fi = red_i[w]; fp = red_p[w];
+                }
+            if (fp >= 0) {
+                topk_idx[(int64_t)q * k + r] = fi;
+                topk_sim[(int64_t)q * k + r] = fv;
+                pool[fp].idx = -1;     // taken
+            } else {
+                topk_idx[(int64_t)q * k + r] = -1;
+                topk_sim[(int64_t)q * k + r] = -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (moments) {
+        float s = 0.f, s2 = 0.f, m = -INFINITY, c = 0.f;
+        for (int ch = t; ch < S; ch += 256) {
+            const float* p = mom_part + ((int64_t)ch * M + q) * 4;
+            s += p[0]; s2 += p[1]; m = fmaxf(m, p[2]); c += p[3];
+        }
+        s = wave_sum(s); s2 = wave_sum(s2); c = wave_sum(c); m = wave_max(m);
+        if (lane == 0) { mom_red[wave][0] = s; mom_red[wave][1] = s2; mom_red[wave][2] = m; mom_red[wave][3] = c; }
+        __syncthreads();
+        if (t == 0) {
+            float* o = moments + (int64_t)q * 4;
+            o[0] = mom_red[0][0] + mom_red[1][0] + mom_red[2][0] + mom_red[3][0];
+            o[1] = mom_red[0][1] + mom_red[1][1] + mom_red[2][1] + mom_red[3][1];
+            o[2] = fmaxf(fmaxf(mom_red[0][2], mom_red[1][2]), fmaxf(mom_red[2][2], mom_red[3][2]));
+            o[3] = mom_red[0][3] + mom_red[1][3] + mom_red[2][3] + mom_red[3][3];
+        }
+    }
+}
+
+hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t st = hipFuncSetAttribute((const void*)bank_search_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
+        if (st != hipSuccess) return st;
+        attr_done = true;
+    }
+    const int D = L.D;
+    // products: (bank plane, query plane) pairs accumulated into one tile
+    //   bf16 bank : b.qhi + b.qlo
+    //   fp32 bank : bhi.qhi + bhi.qlo + blo.qhi
+    const int planes = (L.bank_planes == 2) ? 3 : 2;
+    const int a_off[4] = {0, 0, D, 0};          // bank plane offsets
+    const int b_off[4] = {0, D, 0, 0};          // query plane offsets
+
+    // ---- pass 0: sample GEMM + tau ----------------------------------------
+    GemmLaunch G;
+    G.A = L.bank; G.lda = L.ldb * (int64_t)L.sample_stride; G.I = L.n_sample;
+    G.B = L.qplanes; G.ldb = 2 * (int64_t)D; G.J = L.M; G.K = D; G.planes = planes;
+    for (int p = 0; p < 4; ++p) { G.a_plane_off[p] = a_off[p]; G.b_plane_off[p] = b_off[p]; }
+    G.out = L.s0; G.ldo = L.n_sample; G.epilogue = TVC_EPI_F32;
+    hipError_t st = launch_gemm_bf16(G, stream);
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL(kth_bound_kernel, dim3(L.M), dim3(256), 0, stream, L.s0, L.n_sample, L.k, L.tau);
+    st = hipGetLastError();
+    if (st != hipSuccess) return st;
+    st = hipMemsetAsync(L.overflow, 0, sizeof(int32_t), stream);
+    if (st != hipSuccess) return st;
+
+    // ---- pass 1: fused GEMM + filter ---------------------------------------
+    GemmOperands g;
+    g.A = L.bank; g.lda = L.ldb; g.I = (int)L.R;
+    g.B = L.qplanes; g.ldb = 2 * (int64_t)D; g.J = L.M;
+    g.ksteps_per_plane = D / GEMM_BK; g.planes = planes;
+    for (int p = 0; p < 4; ++p) { g.a_plane_off[p] = a_off[p]; g.b_plane_off[p] = b_off[p]; }
+    BankEpilogue e;
+    e.tau = L.tau; e.cand = (Cand*)L.cand; e.cand_cnt = L.cand_cnt; e.mom_part = L.mom_part;
+    e.overflow = L.overflow; e.R = L.R; e.idx_offset = L.idx_offset; e.M = L.M; e.count_thr = L.count_thr;
+    const int nQt = (L.M + GEMM_BN - 1) / GEMM_BN;
+    const int nbt = (int)((L.R + GEMM_BM - 1) / GEMM_BM);
+    const int tpc = (nbt + L.S - 1) / L.S;
+    hipLaunchKernelGGL(bank_search_kernel, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
+                       g, e, nQt, L.S, tpc, nbt);
+    st = hipGetLastError();
+    if (st != hipSuccess) return st;
+
+    // ---- pass 2: select -----------------------------------------------------
+    hipLaunchKernelGGL(bank_select_kernel, dim3(L.M), dim3(256), 0, stream, (const Cand*)L.cand,
+                       L.cand_cnt, L.mom_part, L.S, L.M, L.k, L.topk_idx, L.topk_sim, L.moments, L.overflow);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// merge of W per-shard partial top-k lists (bank sharded over GPUs)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t* __restrict__ idx_parts,
+                                                         const float* __restrict__ sim_parts,
+                                                         const float* __restrict__ feat_parts,
+                                                         const float* __restrict__ mom_parts, int W,
+                                                         int M, int k, int kf, int D,
+                                                         int32_t* __restrict__ idx_out,
+                                                         float* __restrict__ sim_out,
+                                                         float* __restrict__ feat_out,
+                                                         float* __restrict__ mom_out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ int src_of_rank[32];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int n = W * k;   // <= 256
+    float v = -INFINITY;
+    int id = -1;
+    if (t < n) {
+        const int w = t / k, j = t - w * k;
+        id = idx_parts[((int64_t)w * M + q) * k + j];
+        v = (id >= 0) ? sim_parts[((int64_t)w * M + q) * k + j] : -INFINITY;
+    }
+    sv[t] = v; si[t] = id;
+    if (t < 32) src_of_rank[t] = -1;
+    __syncthreads();
+    if (t < n) {
+        int rank = 0;
+        for (int u = 0; u < n; ++u) {
+            if (u == t) continue;
+            const float ov = sv[u]; const int oi = si[u];
+            // entries with idx < 0 sort last; among valid: (v desc, idx asc); stable by position
+            bool before;
+            if (oi < 0) before = false;
+            else if (id < 0) before = true;
+            else before = (ov > v) || (ov == v && (oi < id || (oi == id && u < t)));
+            rank += before ? 1 : 0;
+        }
+        if (id < 0) {
+            // padded entries: count how many padded entries precede (keep ranks unique)
+            int valid = 0, pad_before = 0;
+            for (int u = 0; u < n; ++u) { valid += (si[u] >= 0); pad_before += (si[u] < 0 && u < t); }
+            rank = valid + pad_before;
+        }
+        if (rank < k) {
+            idx_out[(int64_t)q * k + rank] = id;
+            sim_out[(int64_t)q * k + rank] = v;
+            if (rank < kf) src_of_rank[rank] = t;
+        }
+    }
+    __syncthreads();
+    if (feat_out && feat_parts) {
+        for (int r = 0; r < kf; ++r) {
+            const int s = src_of_rank[r];
+            float* o = feat_out + ((int64_t)q * kf + r) * D;
+            if (s < 0 || si[s] < 0) {
+                for (int c = t; c < D; c += 256) o[c] = 0.f;
+            } else {
+                const int w = s / k, j = s - w * k;
+                // a global rank < kf implies a shard-local rank < kf
+                const float* f = feat_parts + (((int64_t)w * M + q) * kf + (j < kf ? j : kf - 1)) * D;
+                for (int c = t; c < D; c += 256) o[c] = f[c];
+            }
+        }
+    }
+    if (mom_out && mom_parts && t == 0) {
+        float s = 0.f, s2 = 0.f, m = -INFINITY, c = 0.f;
+        for (int w = 0; w < W; ++w) {
+            const float* p = mom_parts + ((int64_t)w * M + q) * 4;
+            s += p[0]; s2 += p[1]; m = fmaxf(m, p[2]); c += p[3];
+        }
+        float* o = mom_out + (int64_t)q * 4;
+        o[0] = s; o[1] = s2; o[2] = m; o[3] = c;
+    }
+}
+
+hipError_t launch_topk_merge(const int32_t* idx_parts, const float* sim_parts, const float* feat_parts,
+                             const float* mom_parts, int W, int M, int k, int kf, int D,
+                             int32_t* idx_out, float* sim_out, float* feat_out, float* mom_out,
+                             hipStream_t stream) {
+    if (M == 0) return hipSuccess;
+    if (W < 1 || k < 1 || k > 32 || W * k > 256 || kf < 0 || kf > k) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(M), dim3(256), 0, stream, idx_parts, sim_parts, feat_parts,
+                       mom_parts, W, M, k, kf, D, idx_out, sim_out, feat_out, mom_out);
+    return hipGetLastError();
+}

@@ -1,0 +1,181 @@
+// K4 + K6 + K7: per-query text-variant consistency, retrieval-reference
+// consistency (gather, greedy de-duplication, cosine with the image row) and the
+// stateless parts of both score polarities, one workgroup (4 waves) per query.
+// Everything is tiny ((N+1) + ~45 dot products of length D); the point of the
+// kernel is that no per-variant `.item()` host round trip remains
+// (reference: src/detector.py:461-471, experiments/defenses/detector.py:244-266).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define CONS_MAX_TEXT 40      // N + 1 <= 40
+#define CONS_MAX_CAND 320     // (N + 1) * reference_count
+#define CONS_MAX_REF 16
+#define COS_EPS 1e-8f         // torch.cosine_similarity clamps each norm to eps
+
+struct Dot3 { float ab, aa, bb; };
+
+__device__ __forceinline__ Dot3 wave_dot3(const float* __restrict__ a, const float* __restrict__ b, int D, int lane) {
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float x = a[c], y = b[c];
+        ab = fmaf(x, y, ab); aa = fmaf(x, x, aa); bb = fmaf(y, y, bb);
+    }
+    Dot3 r;
+    r.ab = wave_sum(ab); r.aa = wave_sum(aa); r.bb = wave_sum(bb);
+    return r;
+}
+
+__device__ __forceinline__ float cos_from(const Dot3& d) {
+    const float na = fmaxf(sqrtf(d.aa), COS_EPS), nb = fmaxf(sqrtf(d.bb), COS_EPS);
+    return d.ab / (na * nb);
+}
+
+__global__ __launch_bounds__(256) void consistency_kernel(const float* __restrict__ img,
+                                                          const float* __restrict__ txt, int B, int N, int D,
+                                                          const int32_t* __restrict__ ref_idx,
+                                                          const float* __restrict__ ref_sim,
+                                                          const float* __restrict__ ref_feat, int ks, int kf,
+                                                          ConsistencyParams P, float* __restrict__ rec,
+                                                          int rec_stride) {
+    __shared__ float sims[CONS_MAX_TEXT];
+    __shared__ int cand_slot[CONS_MAX_CAND];   // feature slot n*kf + j
+    __shared__ int cand_idx[CONS_MAX_CAND];
+    __shared__ int n_cand;
+    __shared__ int uniq_slot[CONS_MAX_REF];
+    __shared__ int uniq_idx[CONS_MAX_REF];
+    __shared__ float uniq_cos[CONS_MAX_REF];
+    __shared__ int n_uniq;
+    __shared__ int dup_flag;
+
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int N1 = N + 1;
+    const float* im = img + (int64_t)b * D;
+    const float* tx = txt + (int64_t)b * N1 * D;
+
+    // K4: cos(image, text_n)
+    for (int n = wave; n < N1; n += 4) {
+        const Dot3 d = wave_dot3(im, tx + (int64_t)n * D, D, lane);
+        if (lane == 0) sims[n] = cos_from(d);
+    }
+    if (t == 0) {
+        int nc = 0;
+        if (ks > 0 && ref_idx && ref_feat) {
+            int take = P.reference_count;
+            if (take > ks) take = ks;
+            if (take > kf) take = kf;
+            for (int n = 0; n < N1; ++n) {
+                const int64_t base = ((int64_t)b * N1 + n) * ks;
+                for (int j = 0; j < take; ++j) {
+                    const int id = ref_idx[base + j];
+                    // retrieval_ref.py:210-216: keep sim >= threshold, first reference_count
+                    if (id >= 0 && ref_sim[base + j] >= P.similarity_threshold && nc < CONS_MAX_CAND) {
+                        cand_slot[nc] = n * kf + j;
+                        cand_idx[nc] = id;
+                        ++nc;
+                    }
+                }
+            }
+        }
+        n_cand = nc;
+        n_uniq = 0;
+        dup_flag = 0;
+    }
+    __syncthreads();
+
+    // K6: greedy de-duplication (experiments/defenses/detector.py:302-325), cut to
+    // retrieval_top_k (:200).  Later candidates never evict earlier ones, so
+    // stopping at retrieval_top_k uniques equals dedupe-then-slice.
+    const float* feats = ref_feat ? ref_feat + (int64_t)b * N1 * kf * D : nullptr;
+    const int ncand = n_cand;
+    int top = P.retrieval_top_k < CONS_MAX_REF ? P.retrieval_top_k : CONS_MAX_REF;
+    for (int c = 0; c < ncand; ++c) {
+        const int nu = n_uniq;
+        if (nu >= top) break;
+        const float* fc = feats + (int64_t)cand_slot[c] * D;
+        for (int u = wave; u < nu; u += 4) {
+            const Dot3 d = wave_dot3(fc, feats + (int64_t)uniq_slot[u] * D, D, lane);
+            if (lane == 0 && cos_from(d) > P.dup_threshold) atomicOr(&dup_flag, 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            if (!dup_flag) {
+                uniq_slot[nu] = cand_slot[c];
+                uniq_idx[nu] = cand_idx[c];
+                n_uniq = nu + 1;
+            }
+            dup_flag = 0;
+        }
+        __syncthreads();
+    }
+    const int nu = n_uniq;
+    for (int u = wave; u < nu; u += 4) {
+        const Dot3 d = wave_dot3(im, feats + (int64_t)uniq_slot[u] * D, D, lane);
+        if (lane == 0) uniq_cos[u] = cos_from(d);
+    }
+    __syncthreads();
+
+    if (t == 0) {
+        float* r = rec + (int64_t)b * rec_stride;
+        const double s0 = sims[0];
+        double mean = s0, sd = 0.0;
+        if (N > 0) {
+            double acc = 0.0;
+            for (int n = 1; n <= N; ++n) acc += sims[n];
+            mean = acc / N;
+            double var = 0.0;
+            for (int n = 1; n <= N; ++n) { const double dl = sims[n] - mean; var += dl * dl; }
+            sd = sqrt(var / N);
+        }
+        // src polarity (src/detector.py:479-485, 579, 664-680)
+        const double consistency = 1.0 - fabs(s0 - mean);
+        const double variability = 1.0 - sd;
+        const double tv = 1.0 - (consistency * 0.7 + variability * 0.3);
+        const double cs = 1.0 - s0;
+        double agg;
+        if (N > 0) agg = (tv * P.w_text_variants + cs * P.w_consistency) / ((double)P.w_text_variants + P.w_consistency);
+        else agg = cs;
+        // exp polarity (experiments/defenses/detector.py:251-300)
+        double rmean = 0.0, rsd = 0.0;
+        if (nu > 0) {
+            double acc = 0.0;
+            for (int u = 0; u < nu; ++u) acc += uniq_cos[u];
+            rmean = acc / nu;
+            double var = 0.0;
+            for (int u = 0; u < nu; ++u) { const double dl = uniq_cos[u] - rmean; var += dl * dl; }
+            rsd = sqrt(var / nu);
+        }
+        const double four[4] = {s0, mean, rmean, 0.0};   // generative refs are out of scope
+        double vs = 0.0; int nv = 0;
+        for (int i = 0; i < 4; ++i) if (four[i] > 0) { vs += four[i]; ++nv; }
+        double xvar = 0.0;
+        if (nv >= 2) {
+            const double mu = vs / nv;
+            for (int i = 0; i < 4; ++i) if (four[i] > 0) xvar += (four[i] - mu) * (four[i] - mu);
+            xvar /= nv;
+        }
+        double ws = 0.0, tw = 0.0;   // consistency_checker.py:147-160
+        for (int i = 0; i < 4; ++i) if (four[i] > 0) { ws += four[i] * P.w_exp[i]; tw += P.w_exp[i]; }
+        const double overall = (tw != 0.0) ? ws / tw : 0.0;
+
+        r[0] = (float)s0; r[1] = (float)mean; r[2] = (float)sd; r[3] = (float)tv; r[4] = (float)cs;
+        r[5] = (float)agg; r[6] = (float)rmean; r[7] = (float)rsd; r[8] = (float)nu; r[9] = (float)xvar;
+        r[10] = (float)overall; r[11] = 0.f;
+        for (int n = 0; n < N; ++n) r[12 + n] = sims[n + 1];
+        for (int u = 0; u < CONS_MAX_REF; ++u) {
+            r[12 + N + u] = __int_as_float(u < nu ? uniq_idx[u] : -1);
+            r[12 + N + CONS_MAX_REF + u] = u < nu ? uniq_cos[u] : 0.f;
+        }
+    }
+}
+
+hipError_t launch_consistency(const float* img, const float* txt, int B, int N, int D,
+                              const int32_t* ref_idx, const float* ref_sim, const float* ref_feat,
+                              int ks, int kf, const ConsistencyParams& p, float* rec, int rec_stride,
+                              hipStream_t stream) {
+    if (B == 0) return hipSuccess;
+    if (N < 0 || N + 1 > CONS_MAX_TEXT || (N + 1) * p.reference_count > CONS_MAX_CAND) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(consistency_kernel, dim3(B), dim3(256), 0, stream, img, txt, B, N, D, ref_idx, ref_sim,
+                       ref_feat, ks, kf, p, rec, rec_stride);
+    return hipGetLastError();
+}

@@ -1,0 +1,339 @@
+// HBM-bound row kernels of the CLIP towers and the bank path: LayerNorm,
+// patch im2col, token assembly, embedding gather, L2 normalise, split-bf16
+// planes, bank row gather.  One 64-lane wave per row, 16-byte accesses,
+// wave-shuffle reductions (no LDS).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define LN_EPS 1e-5f
+#define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 rows
+
+// ---------------------------------------------------------------------------
+// LayerNorm: fp32 row -> bf16 row (GEMM operand).  d % 4 == 0, d <= 1024.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
+                                                        const int32_t* __restrict__ row_idx,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b,
+                                                        uint16_t* __restrict__ y, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t src_row = row_idx ? (int64_t)row_idx[row] : (int64_t)row;
+    const f32x4_t* xr = (const f32x4_t*)(x + src_row * x_row_stride);
+    const int nv = d >> 2;
+    f32x4_t v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[i] = xr[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float dlt = v[i][t] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + LN_EPS);
+    u32x2_t* yr = (u32x2_t*)(y + (int64_t)row * d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4_t gg = ((const f32x4_t*)g)[c];
+            const f32x4_t bb = ((const f32x4_t*)b)[c];
+            f32x4_t o;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = (v[i][t] - mean) * rstd * gg[t] + bb[t];
+            u32x2_t pk;
+            pk[0] = pack_bf16x2(o[0], o[1]);
+            pk[1] = pack_bf16x2(o[2], o[3]);
+            yr[c] = pk;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const int32_t* row_idx,
+                            const float* g, const float* b, uint16_t* y, int rows, int d,
+                            hipStream_t stream) {
+    if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, g, b, y, rows, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// im2col for the stride=patch conv: pix fp32 [B,3,S,S] -> bf16 [B*P, Kp],
+// column order (c, ky, kx) = the conv weight's flatten order; zero padded.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix,
+                                                     uint16_t* __restrict__ out, int B, int S,
+                                                     int patch, int Kp) {
+    const int g = S / patch;           // patches per side
+    const int P = g * g;
+    const int chunks = Kp >> 3;        // 8 columns (16 B) per thread
+    const int64_t total = (int64_t)B * P * chunks;
+    const int K = 3 * patch * patch;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % chunks);
+        const int64_t row = t / chunks;
+        const int p = (int)(row % P);
+        const int bimg = (int)(row / P);
+        const int py = p / g, px = p - py * g;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float f[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = ch * 8 + e * 2 + h;
+                float val = 0.f;
+                if (col < K) {
+                    const int c = col / (patch * patch);
+                    const int rem = col - c * patch * patch;
+                    const int ky = rem / patch, kx = rem - ky * patch;
+                    val = pix[(((int64_t)bimg * 3 + c) * S + (py * patch + ky)) * S + (px * patch + kx)];
+                }
+                f[h] = val;
+            }
+            w[e] = pack_bf16x2(f[0], f[1]);
+        }
+        *(u32x4_t*)(out + row * Kp + ch * 8) = u32x4_t{w[0], w[1], w[2], w[3]};
+    }
+}
+
+hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
+                         hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    const int g = image / patch;
+    const int64_t total = (int64_t)B * g * g * (Kp >> 3);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, pix, out, B, image, patch, Kp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// x[b, t, :] = ln_pre( (t == 0 ? cls : patch_out[b, t-1, :]) + pos[t, :] )
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_lnpre_kernel(const float* __restrict__ patch_out,
+                                                             const float* __restrict__ cls,
+                                                             const float* __restrict__ pos,
+                                                             const float* __restrict__ g,
+                                                             const float* __restrict__ b,
+                                                             float* __restrict__ x, int B, int T, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * T) return;
+    const int t = (int)(row % T);
+    const int64_t bimg = row / T;
+    const f32x4_t* src = (t == 0) ? (const f32x4_t*)cls
+                                  : (const f32x4_t*)(patch_out + (bimg * (T - 1) + (t - 1)) * d);
+    const f32x4_t* pr = (const f32x4_t*)(pos + (int64_t)t * d);
+    const int nv = d >> 2;
+    f32x4_t v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            v[i] = src[c] + pr[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dl = v[i][e] - mean;
+                q += dl * dl;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + LN_EPS);
+    f32x4_t* xr = (f32x4_t*)(x + row * d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4_t gg = ((const f32x4_t*)g)[c];
+            const f32x4_t bb = ((const f32x4_t*)b)[c];
+            f32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            xr[c] = o;
+        }
+    }
+}
+
+hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
+                                 const float* g, const float* b, float* x, int B, int T, int d,
+                                 hipStream_t stream) {
+    if (d % 4 != 0 || d > 1024) return hipErrorInvalidValue;
+    const int64_t rows = (int64_t)B * T;
+    if (rows == 0) return hipSuccess;
+    const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(assemble_lnpre_kernel, dim3(grid), dim3(256), 0, stream, patch_out, cls, pos, g, b, x, B, T, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// text embedding: x[n, t, :] = tok_emb[tok[n, t], :] + pos[t, :];
+// eot_row[n] = n*ctx + argmax_t tok[n, t]  (first maximum, as torch.argmax)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tok,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos,
+                                                         float* __restrict__ x,
+                                                         int32_t* __restrict__ eot_row, int n_text,
+                                                         int ctx, int d, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (int64_t)n_text * ctx) return;
+    const int t = (int)(row % ctx);
+    const int64_t n = row / ctx;
+    int id = tok[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4_t* er = (const f32x4_t*)(tok_emb + (int64_t)id * d);
+    const f32x4_t* pr = (const f32x4_t*)(pos + (int64_t)t * d);
+    f32x4_t* xr = (f32x4_t*)(x + row * d);
+    for (int c = lane; c < (d >> 2); c += 64) xr[c] = er[c] + pr[c];
+    if (t == 0) {
+        // arg-max over the ctx ids of text n; ties -> lowest position
+        int best = -1, best_t = 0;
+        for (int tt = lane; tt < ctx; tt += 64) {
+            const int v = tok[n * ctx + tt];
+            if (v > best) { best = v; best_t = tt; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ov = __shfl_xor(best, o, 64);
+            const int ot = __shfl_xor(best_t, o, 64);
+            if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
+        }
+        if (lane == 0) eot_row[n] = (int32_t)(n * ctx + best_t);
+    }
+}
+
+hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
+                             int32_t* eot_row, int n_text, int ctx, int d, int vocab,
+                             hipStream_t stream) {
+    if (d % 4 != 0) return hipErrorInvalidValue;
+    const int64_t rows = (int64_t)n_text * ctx;
+    if (rows == 0) return hipSuccess;
+    const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(text_embed_kernel, dim3(grid), dim3(256), 0, stream, tok, tok_emb, pos, x, eot_row, n_text, ctx, d, vocab);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// in-place L2 normalise of fp32 rows: x / ||x||  (no epsilon, as
+// `x / x.norm(dim=-1, keepdim=True)` -- retrieval_ref.py:243)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (int64_t)row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c] * xr[c];
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int c = lane; c < d; c += 64) xr[c] *= inv;
+}
+
+hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(256), 0, stream, x, rows, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// split-bf16 planes: out[r, 0:d] = bf16(x), out[r, d:2d] = bf16(x - hi)
+// (planes == 1: hi only).  x ~= hi + lo to ~2^-17 relative.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x,
+                                                           uint16_t* __restrict__ out, int64_t rows,
+                                                           int d, int planes) {
+    const int nv = d >> 2;
+    const int64_t total = rows * nv;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / nv;
+        const int c = (int)(t - r * nv);
+        const f32x4_t v = ((const f32x4_t*)(x + r * d))[c];
+        float hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = bf16_bits_to_f32(f32_to_bf16_bits(v[e]));
+            lo[e] = v[e] - hi[e];
+        }
+        uint16_t* o = out + r * (int64_t)(planes * d) + c * 4;
+        *(u32x2_t*)o = u32x2_t{pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+        if (planes > 1) *(u32x2_t*)(o + d) = u32x2_t{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3])};
+    }
+}
+
+hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
+                               hipStream_t stream) {
+    if (d % 4 != 0 || planes < 1 || planes > 2) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    const int64_t total = rows * (d >> 2);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, stream, x, out, rows, d, planes);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// bank row gather: out[n, :] = fp32(bank[idx[n] - idx_offset]) (hi + lo)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint16_t* __restrict__ bank, int64_t ld,
+                                                          int planes, int D, int64_t R,
+                                                          const int32_t* __restrict__ idx,
+                                                          int64_t idx_offset, int n,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int64_t src = (int64_t)idx[row] - idx_offset;
+    float* o = out + (int64_t)row * D;
+    if (idx[row] < 0 || src < 0 || src >= R) {
+        for (int c = lane; c < D; c += 64) o[c] = 0.f;
+        return;
+    }
+    const uint16_t* br = bank + src * ld;
+    for (int c = lane; c < D; c += 64) {
+        float v = bf16_bits_to_f32(br[c]);
+        if (planes > 1) v += bf16_bits_to_f32(br[D + c]);
+        o[c] = v;
+    }
+}
+
+hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R,
+                              const int32_t* idx, int64_t idx_offset, int n, float* out,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int grid = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, stream, bank, ld, planes, D, R, idx, idx_offset, n, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,91 @@
+// Host-side launch interface of the TVC HIP kernels (internal; the public
+// boundary is include/tvc.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { TVC_EPI_F32 = 0, TVC_EPI_BF16 = 1, TVC_EPI_GELU_BF16 = 2, TVC_EPI_RESID_F32 = 3 };
+
+struct GemmLaunch {
+    const uint16_t* A = nullptr;   // [I, lda] bf16  (weights / bank rows)
+    const uint16_t* B = nullptr;   // [J, ldb] bf16  (tokens / query rows)
+    int64_t lda = 0, ldb = 0;
+    int I = 0, J = 0, K = 0;       // K per plane, multiple of 64
+    int planes = 1;
+    int a_plane_off[4] = {0, 0, 0, 0};
+    int b_plane_off[4] = {0, 0, 0, 0};
+    const float* bias = nullptr;   // [I]
+    void* out = nullptr;           // [J, ldo]
+    int64_t ldo = 0;
+    int epilogue = TVC_EPI_F32;
+};
+hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
+
+// ---- elementwise.hip
+hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const int32_t* row_idx,
+                            const float* g, const float* b, uint16_t* y, int rows, int d,
+                            hipStream_t stream);
+hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
+                         hipStream_t stream);
+hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
+                                 const float* g, const float* b, float* x, int B, int T, int d,
+                                 hipStream_t stream);
+hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
+                             int32_t* eot_row, int n_text, int ctx, int d, int vocab,
+                             hipStream_t stream);
+hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream);
+hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
+                               hipStream_t stream);
+hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R,
+                              const int32_t* idx, int64_t idx_offset, int n, float* out,
+                              hipStream_t stream);
+
+// ---- attention.hip
+hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, int n_seq, int seq_len, int heads,
+                            int causal, hipStream_t stream);
+
+// ---- bank.hip
+struct BankSearchLaunch {
+    const uint16_t* bank = nullptr;   // [R, ldb] bf16 planes
+    int64_t ldb = 0;
+    int64_t R = 0;
+    int D = 0;
+    int bank_planes = 1;              // 1 = bf16 bank, 2 = (hi | lo) split of an fp32 bank
+    const uint16_t* qplanes = nullptr;// [M, 2*D] bf16 (hi | lo) query planes
+    int M = 0;
+    int k = 0;
+    float count_thr = 0.f;
+    int64_t idx_offset = 0;
+    // workspace (sized by bank_workspace_bytes)
+    float* s0 = nullptr;              // [M, n_sample] pre-pass similarities
+    float* tau = nullptr;             // [M]
+    void* cand = nullptr;             // [S, M, CAP] {float, int}
+    int32_t* cand_cnt = nullptr;      // [S, M]
+    float* mom_part = nullptr;        // [S, M, 4]
+    int32_t* overflow = nullptr;      // [1]
+    int n_sample = 0, sample_stride = 1, S = 0, cap = 0;
+    // outputs
+    int32_t* topk_idx = nullptr;
+    float* topk_sim = nullptr;
+    float* moments = nullptr;
+};
+void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap);
+hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream);
+hipError_t launch_topk_merge(const int32_t* idx_parts, const float* sim_parts, const float* feat_parts,
+                             const float* mom_parts, int W, int M, int k, int kf, int D,
+                             int32_t* idx_out, float* sim_out, float* feat_out, float* mom_out,
+                             hipStream_t stream);
+
+// ---- consistency.hip
+struct ConsistencyParams {
+    int reference_count;
+    float similarity_threshold;
+    int retrieval_top_k;
+    float dup_threshold;
+    float w_text_variants, w_consistency;
+    float w_exp[4];
+};
+hipError_t launch_consistency(const float* img, const float* txt, int B, int N, int D,
+                              const int32_t* ref_idx, const float* ref_sim, const float* ref_feat,
+                              int ks, int kf, const ConsistencyParams& p, float* rec, int rec_stride,
+                              hipStream_t stream);

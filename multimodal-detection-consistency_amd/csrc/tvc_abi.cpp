@@ -1,0 +1,458 @@
+// C-ABI of the TVC hot path (include/tvc.h): handle, workspace and the launch
+// sequences of the CLIP towers, the bank search and the consistency kernel.
+// No torch types, no exceptions across the boundary, no device synchronisation
+// except where tvc.h says so.
+#include "../../include/tvc.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Slot {
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT,
+    WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
+    WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
+    WS_COUNT
+};
+
+struct Buf {
+    void* p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct tvc_handle {
+    tvc_model_desc desc{};
+    bool has_vision = false, has_text = false;
+    tvc_vision_weights vw{};
+    tvc_text_weights tw{};
+    std::vector<tvc_layer_weights> vlayers, tlayers;
+    // bank
+    const uint16_t* bank = nullptr;
+    void* bank_owned = nullptr;
+    int64_t R = 0;
+    int D = 0;
+    int bank_planes = 1;
+    Buf ws[WS_COUNT];
+    std::string err;
+    int max_chunk_images = 512;
+    int max_chunk_texts = 4608;
+};
+
+namespace {
+
+int fail(tvc_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t st__ = (expr);                                                            \
+        if (st__ != hipSuccess)                                                              \
+            return fail(h, TVC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(st__));  \
+    } while (0)
+
+int ensure(tvc_handle* h, Slot s, size_t bytes) {
+    Buf& b = h->ws[s];
+    if (b.n >= bytes && b.p) return TVC_OK;
+    if (b.p) {
+        // hipFree synchronises the device, so kernels still using the old block are done
+        if (hipFree(b.p) != hipSuccess) return fail(h, TVC_E_HIP, "hipFree(workspace) failed");
+        b.p = nullptr; b.n = 0;
+    }
+    // grow with a little slack so alternating sizes do not thrash
+    const size_t want = bytes + bytes / 16 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        char m[128];
+        snprintf(m, sizeof m, "workspace allocation of %zu bytes failed", want);
+        return fail(h, TVC_E_NOMEM, m);
+    }
+    b.n = want;
+    return TVC_OK;
+}
+
+bool tower_ok(const tvc_tower_arch& a) {
+    return a.width > 0 && a.layers > 0 && a.heads > 0 && a.width == a.heads * 64 && a.width % 64 == 0 &&
+           a.width <= 1024 && a.mlp > 0 && a.mlp % 64 == 0;
+}
+
+// One transformer tower over `rows` packed token rows (n_seq sequences of seq_len).
+int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
+               int causal, hipStream_t st) {
+    const int d = a.width;
+    const int64_t rows64 = (int64_t)n_seq * seq_len;
+    const int rows = (int)rows64;
+    float* X = (float*)h->ws[WS_X].p;
+    uint16_t* H = (uint16_t*)h->ws[WS_H].p;
+    uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
+    uint16_t* MLP = (uint16_t*)h->ws[WS_MLP].p;
+    for (int l = 0; l < a.layers; ++l) {
+        const tvc_layer_weights& w = lw[l];
+        HIP_TRY(launch_layernorm(X, d, nullptr, w.ln1_g, w.ln1_b, H, rows, d, st));
+        GemmLaunch g;
+        g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
+        g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(launch_attention(QKV, H, n_seq, seq_len, a.heads, causal, st));
+        g = GemmLaunch();
+        g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
+        g.bias = w.bo; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(launch_layernorm(X, d, nullptr, w.ln2_g, w.ln2_b, H, rows, d, st));
+        g = GemmLaunch();
+        g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
+        g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        g = GemmLaunch();
+        g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
+        g.bias = w.b2; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
+        HIP_TRY(launch_gemm_bf16(g, st));
+    }
+    return TVC_OK;
+}
+
+int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq) {
+    int rc;
+    if ((rc = ensure(h, WS_X, (size_t)rows * a.width * 4))) return rc;
+    if ((rc = ensure(h, WS_H, (size_t)rows * a.width * 2))) return rc;
+    if ((rc = ensure(h, WS_QKV, (size_t)rows * a.width * 3 * 2))) return rc;
+    if ((rc = ensure(h, WS_MLP, (size_t)rows * a.mlp * 2))) return rc;
+    if ((rc = ensure(h, WS_CLS, (size_t)n_seq * a.width * 2))) return rc;
+    return TVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t tvc_abi_version(void) { return TVC_ABI_VERSION; }
+
+const char* tvc_last_error(tvc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision, const tvc_text_weights* text,
+               tvc_handle** out) {
+    tvc_handle* h = nullptr;   // for HIP_TRY / fail before the handle exists
+    if (!out) return fail(h, TVC_E_INVALID, "tvc_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(h, TVC_E_HIP, "tvc_create: no HIP device visible (the TVC path has no CPU fallback)");
+    if ((vision || text) && !desc) return fail(h, TVC_E_INVALID, "tvc_create: weights given without a model desc");
+    tvc_handle* nh = new tvc_handle();
+    if (desc) nh->desc = *desc;
+    if (vision) {
+        const tvc_model_desc& d = *desc;
+        const int Kraw = 3 * d.patch * d.patch;
+        if (!tower_ok(d.vision) || d.patch <= 0 || d.image_size % d.patch != 0 || d.embed_dim % 64 != 0 ||
+            Kraw <= 0 || !vision->layers) {
+            delete nh;
+            return fail(h, TVC_E_INVALID, "tvc_create: unsupported vision geometry (head_dim must be 64, width<=1024)");
+        }
+        const int T = (d.image_size / d.patch) * (d.image_size / d.patch) + 1;
+        if (T > 288) { delete nh; return fail(h, TVC_E_INVALID, "tvc_create: vision sequence longer than 288 tokens"); }
+        nh->vw = *vision;
+        nh->vlayers.assign(vision->layers, vision->layers + d.vision.layers);
+        nh->vw.layers = nh->vlayers.data();
+        nh->has_vision = true;
+    }
+    if (text) {
+        const tvc_model_desc& d = *desc;
+        if (!tower_ok(d.text) || d.ctx <= 0 || d.ctx > 288 || d.vocab <= 0 || d.embed_dim % 64 != 0 || !text->layers) {
+            delete nh;
+            return fail(h, TVC_E_INVALID, "tvc_create: unsupported text geometry");
+        }
+        nh->tw = *text;
+        nh->tlayers.assign(text->layers, text->layers + d.text.layers);
+        nh->tw.layers = nh->tlayers.data();
+        nh->has_text = true;
+    }
+    *out = nh;
+    return TVC_OK;
+}
+
+void tvc_destroy(tvc_handle* h) {
+    if (!h) return;
+    for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
+    if (h->bank_owned) (void)hipFree(h->bank_owned);
+    delete h;
+}
+
+uint64_t tvc_workspace_bytes(tvc_handle* h) {
+    if (!h) return 0;
+    uint64_t n = 0;
+    for (auto& b : h->ws) n += b.n;
+    return n;
+}
+
+int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize,
+                     void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->has_vision) return fail(h, TVC_E_STATE, "tvc_encode_image: handle has no vision tower");
+    if (B < 0 || (B > 0 && (!pix_dev || !out_dev))) return fail(h, TVC_E_INVALID, "tvc_encode_image: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.vision;
+    const int gside = m.image_size / m.patch, P = gside * gside, T = P + 1, d = a.width;
+    const int Kp = (3 * m.patch * m.patch + 63) / 64 * 64;
+    const int chunk = B < h->max_chunk_images ? B : h->max_chunk_images;
+    if (B == 0) return TVC_OK;
+    int rc;
+    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk))) return rc;
+    if ((rc = ensure(h, WS_PATCH, (size_t)chunk * P * Kp * 2))) return rc;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int n = (B - b0 < chunk) ? B - b0 : chunk;
+        const float* pix = pix_dev + (size_t)b0 * 3 * m.image_size * m.image_size;
+        uint16_t* Pm = (uint16_t*)h->ws[WS_PATCH].p;
+        float* patch_out = (float*)h->ws[WS_MLP].p;    // [n*P, d] fp32 fits: mlp >= 2*d
+        if ((size_t)n * P * d * 4 > h->ws[WS_MLP].n) return fail(h, TVC_E_INVALID, "tvc_encode_image: mlp < 2*width unsupported");
+        HIP_TRY(launch_im2col(pix, Pm, n, m.image_size, m.patch, Kp, st));
+        GemmLaunch g;
+        g.A = h->vw.patch_w; g.lda = Kp; g.I = d; g.B = Pm; g.ldb = Kp; g.J = n * P; g.K = Kp;
+        g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
+                                      (float*)h->ws[WS_X].p, n, T, d, st));
+        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, st))) return rc;
+        // ln_post on the class rows, projection, L2 norm
+        uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
+        HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, h->vw.ln_post_g,
+                                 h->vw.ln_post_b, Hc, n, d, st));
+        g = GemmLaunch();
+        g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
+        g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)b0 * m.embed_dim, n, m.embed_dim, st));
+    }
+    return TVC_OK;
+}
+
+int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, int32_t normalize,
+                    void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->has_text) return fail(h, TVC_E_STATE, "tvc_encode_text: handle has no text tower");
+    if (Tn < 0 || (Tn > 0 && (!tok_dev || !out_dev))) return fail(h, TVC_E_INVALID, "tvc_encode_text: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.text;
+    const int d = a.width, ctx = m.ctx;
+    if (Tn == 0) return TVC_OK;
+    const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
+    int rc;
+    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk))) return rc;
+    if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
+    for (int t0 = 0; t0 < Tn; t0 += chunk) {
+        const int n = (Tn - t0 < chunk) ? Tn - t0 : chunk;
+        int32_t* eot = (int32_t*)h->ws[WS_EOT].p;
+        HIP_TRY(launch_text_embed(tok_dev + (size_t)t0 * ctx, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_X].p, eot,
+                                  n, ctx, d, m.vocab, st));
+        if ((rc = run_layers(h, a, h->tw.layers, n, ctx, 1, st))) return rc;
+        uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
+        HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, d, eot, h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
+        GemmLaunch g;
+        g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
+        g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
+        HIP_TRY(launch_gemm_bf16(g, st));
+        if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)t0 * m.embed_dim, n, m.embed_dim, st));
+    }
+    return TVC_OK;
+}
+
+int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D, int32_t dtype, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (R < 0 || R > 0x7fffffffLL || D <= 0 || D % 64 != 0 || (R > 0 && !bank_dev))
+        return fail(h, TVC_E_INVALID, "tvc_bank_set: need 0 <= R < 2^31 and D % 64 == 0");
+    if (h->bank_owned) { HIP_TRY(hipFree(h->bank_owned)); h->bank_owned = nullptr; }
+    h->bank = nullptr; h->R = 0; h->D = D;
+    if (dtype == TVC_DTYPE_BF16) {
+        h->bank = (const uint16_t*)bank_dev; h->bank_planes = 1;
+    } else if (dtype == TVC_DTYPE_F32) {
+        if (R > 0) {
+            HIP_TRY(hipMalloc(&h->bank_owned, (size_t)R * 2 * D * 2));
+            HIP_TRY(launch_split_planes((const float*)bank_dev, (uint16_t*)h->bank_owned, R, D, 2, (hipStream_t)stream));
+        }
+        h->bank = (const uint16_t*)h->bank_owned; h->bank_planes = 2;
+    } else {
+        return fail(h, TVC_E_INVALID, "tvc_bank_set: dtype must be TVC_DTYPE_BF16 or TVC_DTYPE_F32");
+    }
+    h->R = R;
+    return TVC_OK;
+}
+
+int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, float count_thr,
+                    int64_t idx_offset, int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
+                    void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->bank && h->R != 0) return fail(h, TVC_E_STATE, "tvc_bank_search: no bank registered");
+    if (h->D == 0) return fail(h, TVC_E_STATE, "tvc_bank_search: call tvc_bank_set first");
+    if (M < 0 || k < 1 || k > 32 || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_bank_search: need 1 <= k <= 32 and non-NULL buffers");
+    if (M == 0) return TVC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = h->D;
+    if (h->R == 0) {
+        // empty bank: retrieval_ref.py:195-197 returns no references
+        HIP_TRY(hipMemsetAsync(topk_idx_dev, 0xff, (size_t)M * k * 4, st));
+        HIP_TRY(hipMemsetAsync(topk_sim_dev, 0, (size_t)M * k * 4, st));
+        if (moments_dev) HIP_TRY(hipMemsetAsync(moments_dev, 0, (size_t)M * 16, st));
+        return TVC_OK;
+    }
+    BankSearchLaunch L;
+    bank_plan(h->R, M, k, &L.n_sample, &L.sample_stride, &L.S, &L.cap);
+    int rc;
+    if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
+    if ((rc = ensure(h, WS_S0, (size_t)M * L.n_sample * 4))) return rc;
+    if ((rc = ensure(h, WS_TAU, (size_t)M * 4))) return rc;
+    if ((rc = ensure(h, WS_CAND, (size_t)L.S * M * L.cap * 8))) return rc;
+    if ((rc = ensure(h, WS_CAND_CNT, (size_t)L.S * M * 4))) return rc;
+    if ((rc = ensure(h, WS_MOM_PART, (size_t)L.S * M * 16))) return rc;
+    if ((rc = ensure(h, WS_OVERFLOW, 16))) return rc;
+    HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
+    L.bank = h->bank; L.ldb = (int64_t)h->bank_planes * D; L.R = h->R; L.D = D; L.bank_planes = h->bank_planes;
+    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
+    L.idx_offset = idx_offset;
+    L.s0 = (float*)h->ws[WS_S0].p; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
+    L.cand_cnt = (int32_t*)h->ws[WS_CAND_CNT].p; L.mom_part = (float*)h->ws[WS_MOM_PART].p;
+    L.overflow = (int32_t*)h->ws[WS_OVERFLOW].p;
+    L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
+    HIP_TRY(launch_bank_search(L, st));
+    return TVC_OK;
+}
+
+int tvc_bank_status(tvc_handle* h, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (!h->ws[WS_OVERFLOW].p) return TVC_OK;
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, h->ws[WS_OVERFLOW].p, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        char m[160];
+        snprintf(m, sizeof m, "tvc_bank_search: candidate lists overflowed (flag %d): bank has too many "
+                              "near-identical rows for the sampled bound", flag);
+        return fail(h, TVC_E_OVERFLOW, m);
+    }
+    return TVC_OK;
+}
+
+int tvc_bank_gather(tvc_handle* h, const int32_t* idx_dev, int32_t n, int64_t idx_offset, float* out_dev,
+                    void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (h->D == 0) return fail(h, TVC_E_STATE, "tvc_bank_gather: call tvc_bank_set first");
+    if (n < 0 || (n > 0 && (!idx_dev || !out_dev))) return fail(h, TVC_E_INVALID, "tvc_bank_gather: bad arguments");
+    if (n == 0) return TVC_OK;
+    if (h->R == 0) { HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n * h->D * 4, (hipStream_t)stream)); return TVC_OK; }
+    HIP_TRY(launch_gather_rows(h->bank, (int64_t)h->bank_planes * h->D, h->bank_planes, h->D, h->R, idx_dev,
+                               idx_offset, n, out_dev, (hipStream_t)stream));
+    return TVC_OK;
+}
+
+int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim_parts_dev,
+                   const float* feat_parts_dev, const float* mom_parts_dev, int32_t W, int32_t M, int32_t k,
+                   int32_t kf, int32_t D, int32_t* idx_out_dev, float* sim_out_dev, float* feat_out_dev,
+                   float* mom_out_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (M < 0 || !idx_parts_dev || !sim_parts_dev || !idx_out_dev || !sim_out_dev)
+        return fail(h, TVC_E_INVALID, "tvc_topk_merge: bad arguments");
+    hipError_t st = launch_topk_merge(idx_parts_dev, sim_parts_dev, feat_parts_dev, mom_parts_dev, W, M, k, kf, D,
+                                      idx_out_dev, sim_out_dev, feat_out_dev, mom_out_dev, (hipStream_t)stream);
+    if (st != hipSuccess) return fail(h, st == hipErrorInvalidValue ? TVC_E_INVALID : TVC_E_HIP,
+                                      std::string("tvc_topk_merge: ") + hipGetErrorString(st));
+    return TVC_OK;
+}
+
+int tvc_cosine_matrix(tvc_handle* h, const float* x_dev, int32_t N, const float* y_dev, int32_t M, int32_t D,
+                      float* out_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (N < 0 || M < 0 || D <= 0 || D % 64 != 0 || ((N > 0 && M > 0) && (!x_dev || !y_dev || !out_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_cosine_matrix: need D % 64 == 0 and non-NULL buffers");
+    if (N == 0 || M == 0) return TVC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure(h, WS_COSX, (size_t)N * D * 4))) return rc;
+    if ((rc = ensure(h, WS_COSY, (size_t)M * D * 4))) return rc;
+    if ((rc = ensure(h, WS_COSXP, (size_t)N * D * 4))) return rc;
+    if ((rc = ensure(h, WS_COSYP, (size_t)M * D * 4))) return rc;
+    float* xn = (float*)h->ws[WS_COSX].p;
+    float* yn = (float*)h->ws[WS_COSY].p;
+    HIP_TRY(hipMemcpyAsync(xn, x_dev, (size_t)N * D * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(yn, y_dev, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(launch_l2norm_rows(xn, N, D, st));
+    HIP_TRY(launch_l2norm_rows(yn, M, D, st));
+    uint16_t* xp = (uint16_t*)h->ws[WS_COSXP].p;
+    uint16_t* yp = (uint16_t*)h->ws[WS_COSYP].p;
+    HIP_TRY(launch_split_planes(xn, xp, N, D, 2, st));
+    HIP_TRY(launch_split_planes(yn, yp, M, D, 2, st));
+    // out[n, m]: "A rows" (fast output dim) = y, "B rows" = x; hi.hi + hi.lo + lo.hi
+    GemmLaunch g;
+    g.A = yp; g.lda = 2 * (int64_t)D; g.I = M; g.B = xp; g.ldb = 2 * (int64_t)D; g.J = N; g.K = D; g.planes = 3;
+    g.a_plane_off[0] = 0; g.a_plane_off[1] = 0; g.a_plane_off[2] = D;
+    g.b_plane_off[0] = 0; g.b_plane_off[1] = D; g.b_plane_off[2] = 0;
+    g.out = out_dev; g.ldo = M; g.epilogue = TVC_EPI_F32;
+    HIP_TRY(launch_gemm_bf16(g, st));
+    return TVC_OK;
+}
+
+int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev, int32_t B, int32_t N, int32_t D,
+                    const int32_t* ref_idx_dev, const float* ref_sim_dev, const float* ref_feat_dev, int32_t ks,
+                    int32_t kf, const tvc_consistency_params* params, float* rec_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (B < 0 || N < 0 || D <= 0 || !params || (B > 0 && (!img_dev || !txt_dev || !rec_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_consistency: bad arguments");
+    if (ks > 0 && (!ref_idx_dev || !ref_sim_dev || !ref_feat_dev || kf < 1))
+        return fail(h, TVC_E_INVALID, "tvc_consistency: ks > 0 needs ref_idx, ref_sim, ref_feat and kf >= 1");
+    ConsistencyParams p;
+    p.reference_count = params->reference_count;
+    p.similarity_threshold = params->similarity_threshold;
+    p.retrieval_top_k = params->retrieval_top_k;
+    p.dup_threshold = params->dup_threshold;
+    p.w_text_variants = params->w_text_variants;
+    p.w_consistency = params->w_consistency;
+    for (int i = 0; i < 4; ++i) p.w_exp[i] = params->w_exp[i];
+    if (p.retrieval_top_k > TVC_REC_MAXREF || p.retrieval_top_k < 0 || p.reference_count < 0)
+        return fail(h, TVC_E_INVALID, "tvc_consistency: retrieval_top_k must be in [0, 16]");
+    hipError_t st = launch_consistency(img_dev, txt_dev, B, N, D, ref_idx_dev, ref_sim_dev, ref_feat_dev, ks, kf, p,
+                                       rec_dev, tvc_rec_stride(N), (hipStream_t)stream);
+    if (st != hipSuccess) return fail(h, st == hipErrorInvalidValue ? TVC_E_INVALID : TVC_E_HIP,
+                                      std::string("tvc_consistency: ") + hipGetErrorString(st));
+    return TVC_OK;
+}
+
+int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev, const float* bias_dev, void* out_dev,
+                  int32_t I, int32_t J, int32_t K, int32_t ld_out, int32_t epilogue, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (I <= 0 || J <= 0 || K <= 0 || K % 64 != 0 || !a_dev || !b_dev || !out_dev || ld_out < I ||
+        epilogue < 0 || epilogue > 3)
+        return fail(h, TVC_E_INVALID, "tvc_gemm_bf16: need K % 64 == 0, ld_out >= I");
+    GemmLaunch g;
+    g.A = a_dev; g.lda = K; g.I = I; g.B = b_dev; g.ldb = K; g.J = J; g.K = K;
+    g.bias = bias_dev; g.out = out_dev; g.ldo = ld_out; g.epilogue = epilogue;
+    HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream));
+    return TVC_OK;
+}
+
+int tvc_attention(tvc_handle* h, const uint16_t* qkv_dev, uint16_t* out_dev, int32_t n_seq, int32_t seq_len,
+                  int32_t heads, int32_t causal, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!qkv_dev || !out_dev) return fail(h, TVC_E_INVALID, "tvc_attention: NULL buffer");
+    HIP_TRY(launch_attention(qkv_dev, out_dev, n_seq, seq_len, heads, causal, (hipStream_t)stream));
+    return TVC_OK;
+}
+
+int tvc_layernorm(tvc_handle* h, const float* x_dev, const float* g_dev, const float* b_dev, uint16_t* y_dev,
+                  int32_t rows, int32_t d, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!x_dev || !g_dev || !b_dev || !y_dev) return fail(h, TVC_E_INVALID, "tvc_layernorm: NULL buffer");
+    HIP_TRY(launch_layernorm(x_dev, d, nullptr, g_dev, b_dev, y_dev, rows, d, (hipStream_t)stream));
+    return TVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+"""``TVCEngine``: one C-ABI handle on one GPU, plus the tensor plumbing around it.
+
+PyTorch-ROCm is used for device memory and streams only: every computation on
+the hot path is a HIP kernel launched through ``include/tvc.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .arch import ClipArch
+
+
+@dataclass
+class ConsistencyConfig:
+    """Fields of the reference configs the consistency stage reads."""
+    reference_count: int = 5             # experiments/defenses/retrieval_ref.py:23
+    similarity_threshold: float = 0.3    # retrieval_ref.py:24
+    retrieval_top_k: int = 10            # experiments/defenses/detector.py:29
+    dup_threshold: float = 0.95          # experiments/defenses/detector.py:318
+    w_text_variants: float = 0.4         # src/detector.py:667
+    w_consistency: float = 0.2           # src/detector.py:669
+    w_exp: Tuple[float, float, float, float] = (0.25, 0.25, 0.25, 0.25)   # consistency_checker.py:61-66
+    search_k: int = 5                    # rows searched per text; >= reference_count
+
+    def to_c(self) -> _lib.ConsistencyParams:
+        p = _lib.ConsistencyParams()
+        p.reference_count = self.reference_count
+        p.similarity_threshold = self.similarity_threshold
+        p.retrieval_top_k = self.retrieval_top_k
+        p.dup_threshold = self.dup_threshold
+        p.w_text_variants = self.w_text_variants
+        p.w_consistency = self.w_consistency
+        for i, w in enumerate(self.w_exp):
+            p.w_exp[i] = w
+        return p
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); the TVC path has no CPU fallback")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class TVCEngine:
+    """Owns a ``tvc_handle`` and the device copies of the tower weights."""
+
+    def __init__(self, arch: Optional[ClipArch] = None, vision_w: Optional[Dict] = None,
+                 text_w: Optional[Dict] = None, device: str = "cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.TVCError(_lib.TVC_E_HIP, "no GPU visible to PyTorch-ROCm; the TVC path has no CPU fallback")
+        self.device = torch.device(device)
+        self.arch = arch
+        self._lock = threading.Lock()
+        self._keep = []          # device tensors / ctypes objects referenced by the handle
+        self._bank = None
+        self.bank_rows = 0
+        self.bank_dim = 0
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            desc = vis = txt = None
+            if arch is not None:
+                desc = _lib.ModelDesc(arch.image_size, arch.patch, arch.vocab, arch.ctx, arch.embed_dim,
+                                      _lib.TowerArch(arch.vision.width, arch.vision.layers, arch.vision.heads, arch.vision.mlp),
+                                      _lib.TowerArch(arch.text.width, arch.text.layers, arch.text.heads, arch.text.mlp))
+                if vision_w is not None:
+                    vis = self._vision_struct(arch, vision_w)
+                if text_w is not None:
+                    txt = self._text_struct(arch, text_w)
+            rc = self.lib.tvc_create(C.byref(desc) if desc is not None else None,
+                                     C.byref(vis) if vis is not None else None,
+                                     C.byref(txt) if txt is not None else None, C.byref(self.handle))
+            _lib.check(None, rc)
+
+    # ---- weights -------------------------------------------------------
+    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        d = t.detach().to(device=self.device, dtype=dtype).contiguous()
+        self._keep.append(d)
+        return d
+
+    def _layers(self, layers) -> "C.Array":
+        arr = (_lib.LayerWeights * len(layers))()
+        for i, lw in enumerate(layers):
+            for name in ("ln1_g", "ln1_b", "bqkv", "bo", "ln2_g", "ln2_b", "b1", "b2"):
+                setattr(arr[i], name, self._dev(lw[name], torch.float32).data_ptr())
+            for name in ("wqkv", "wo", "w1", "w2"):
+                setattr(arr[i], name, self._dev(lw[name], torch.bfloat16).data_ptr())
+        self._keep.append(arr)
+        return arr
+
+    def _vision_struct(self, arch: ClipArch, w: Dict) -> _lib.VisionWeights:
+        s = _lib.VisionWeights()
+        pw = torch.zeros((arch.vision.width, arch.patch_k_padded), dtype=torch.float32)
+        pw[:, :arch.patch_k] = w['patch_w'].float().cpu()
+        s.patch_w = self._dev(pw, torch.bfloat16).data_ptr()
+        for name in ("cls", "pos", "ln_pre_g", "ln_pre_b", "ln_post_g", "ln_post_b"):
+            setattr(s, name, self._dev(w[name], torch.float32).data_ptr())
+        s.proj = self._dev(w['proj'], torch.bfloat16).data_ptr()
+        s.layers = C.cast(self._layers(w['layers']), C.POINTER(_lib.LayerWeights))
+        self._keep.append(s)
+        return s
+
+    def _text_struct(self, arch: ClipArch, w: Dict) -> _lib.TextWeights:
+        s = _lib.TextWeights()
+        for name in ("tok_emb", "pos", "ln_final_g", "ln_final_b"):
+            setattr(s, name, self._dev(w[name], torch.float32).data_ptr())
+        s.proj = self._dev(w['proj'], torch.bfloat16).data_ptr()
+        s.layers = C.cast(self._layers(w['layers']), C.POINTER(_lib.LayerWeights))
+        self._keep.append(s)
+        return s
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) and self.handle.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.tvc_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        _lib.check(self.handle, rc)
+
+    # ---- encoders ------------------------------------------------------
+    def encode_image(self, pixels: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """pixels [B, 3, S, S] (preprocessed, on the GPU) -> fp32 [B, D]."""
+        a = self.arch
+        if pixels.dim() == 3:
+            pixels = pixels.unsqueeze(0)
+        if pixels.dim() != 4 or pixels.shape[1:] != (3, a.image_size, a.image_size):
+            raise ValueError(f"expected [B, 3, {a.image_size}, {a.image_size}], got {tuple(pixels.shape)}")
+        pixels = _require_cuda(pixels, torch.float32, "pixels")
+        out = torch.empty((pixels.shape[0], a.embed_dim), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_encode_image(self.handle, _ptr(pixels), pixels.shape[0], _ptr(out),
+                                                  int(normalize), _stream()))
+        return out
+
+    def encode_text(self, tokens: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """tokens int [T, ctx] (on the GPU) -> fp32 [T, D]."""
+        a = self.arch
+        if tokens.dim() != 2 or tokens.shape[1] != a.ctx:
+            raise ValueError(f"expected [T, {a.ctx}] token ids, got {tuple(tokens.shape)}")
+        tokens = _require_cuda(tokens, torch.int32, "tokens")
+        out = torch.empty((tokens.shape[0], a.embed_dim), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_encode_text(self.handle, _ptr(tokens), tokens.shape[0], _ptr(out),
+                                                 int(normalize), _stream()))
+        return out
+
+    # ---- bank ----------------------------------------------------------
+    def set_bank(self, bank: torch.Tensor) -> None:
+        """bank [R, D], rows L2-normalised; bf16 is used in place, fp32 is split
+        into (hi, lo) bf16 planes inside the handle."""
+        if bank.dim() != 2:
+            raise ValueError("bank must be [R, D]")
+        if bank.dtype not in (torch.bfloat16, torch.float32):
+            bank = bank.float()
+        bank = _require_cuda(bank, bank.dtype, "bank")
+        dt = _lib.TVC_DTYPE_BF16 if bank.dtype == torch.bfloat16 else _lib.TVC_DTYPE_F32
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_bank_set(self.handle, _ptr(bank), bank.shape[0], bank.shape[1], dt, _stream()))
+            if dt == _lib.TVC_DTYPE_F32:
+                torch.cuda.current_stream().synchronize()   # the split read `bank`; it may now be freed
+        self._bank = bank if dt == _lib.TVC_DTYPE_BF16 else None
+        self.bank_rows, self.bank_dim = bank.shape
+
+    def bank_search(self, rows: torch.Tensor, k: int, count_thr: float = 0.3, idx_offset: int = 0,
+                    want_moments: bool = True):
+        """rows fp32 [M, D] -> (idx int32 [M, k], sim fp32 [M, k], moments fp32 [M, 4] | None)."""
+        rows = _require_cuda(rows, torch.float32, "rows")
+        M = rows.shape[0]
+        idx = torch.empty((M, k), dtype=torch.int32, device=self.device)
+        sim = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        mom = torch.empty((M, 4), dtype=torch.float32, device=self.device) if want_moments else None
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_bank_search(self.handle, _ptr(rows), M, k, count_thr, idx_offset,
+                                                 _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
+        return idx, sim, mom
+
+    def bank_status(self) -> None:
+        """Synchronise and raise ``TVCError(TVC_E_OVERFLOW)`` if the last search dropped candidates."""
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_bank_status(self.handle, _stream()))
+
+    def bank_gather(self, idx: torch.Tensor, idx_offset: int = 0) -> torch.Tensor:
+        idx = _require_cuda(idx, torch.int32, "idx")
+        n = idx.numel()
+        out = torch.empty((n, self.bank_dim), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_bank_gather(self.handle, _ptr(idx), n, idx_offset, _ptr(out), _stream()))
+        return out.view(*idx.shape, self.bank_dim)
+
+    def topk_merge(self, idx_parts, sim_parts, feat_parts=None, mom_parts=None):
+        """parts [W, M, k] (+ feat [W, M, kf, D], mom [W, M, 4]) -> merged (idx, sim, feat, mom)."""
+        idx_parts = _require_cuda(idx_parts, torch.int32, "idx_parts")
+        sim_parts = _require_cuda(sim_parts, torch.float32, "sim_parts")
+        W, M, k = idx_parts.shape
+        kf, D = (feat_parts.shape[2], feat_parts.shape[3]) if feat_parts is not None else (0, 0)
+        idx = torch.empty((M, k), dtype=torch.int32, device=self.device)
+        sim = torch.empty((M, k), dtype=torch.float32, device=self.device)
+        feat = torch.empty((M, kf, D), dtype=torch.float32, device=self.device) if feat_parts is not None else None
+        mom = torch.empty((M, 4), dtype=torch.float32, device=self.device) if mom_parts is not None else None
+        if feat_parts is not None:
+            feat_parts = _require_cuda(feat_parts, torch.float32, "feat_parts")
+        if mom_parts is not None:
+            mom_parts = _require_cuda(mom_parts, torch.float32, "mom_parts")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_topk_merge(self.handle, _ptr(idx_parts), _ptr(sim_parts), _ptr(feat_parts),
+                                                _ptr(mom_parts), W, M, k, kf, D, _ptr(idx), _ptr(sim), _ptr(feat),
+                                                _ptr(mom), _stream()))
+        return idx, sim, feat, mom
+
+    # ---- consistency ---------------------------------------------------
+    def consistency(self, img: torch.Tensor, txt: torch.Tensor, cfg: ConsistencyConfig,
+                    ref_idx: Optional[torch.Tensor] = None, ref_sim: Optional[torch.Tensor] = None,
+                    ref_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """img [B, D], txt [B, N+1, D]; optional refs for the text rows:
+        ref_idx / ref_sim [B*(N+1), ks], ref_feat [B*(N+1), kf, D].  Returns the
+        record tensor fp32 [B, rec_stride(N)] (layout: include/tvc.h)."""
+        img = _require_cuda(img, torch.float32, "img")
+        txt = _require_cuda(txt, torch.float32, "txt")
+        B, N1, D = txt.shape
+        N = N1 - 1
+        ks = kf = 0
+        if ref_idx is not None:
+            ref_idx = _require_cuda(ref_idx, torch.int32, "ref_idx")
+            ref_sim = _require_cuda(ref_sim, torch.float32, "ref_sim")
+            ref_feat = _require_cuda(ref_feat, torch.float32, "ref_feat")
+            ks, kf = ref_idx.shape[-1], ref_feat.shape[-2]
+        rec = torch.empty((B, _lib.rec_stride(N)), dtype=torch.float32, device=self.device)
+        p = cfg.to_c()
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_consistency(self.handle, _ptr(img), _ptr(txt), B, N, D, _ptr(ref_idx),
+                                                 _ptr(ref_sim), _ptr(ref_feat), ks, kf, C.byref(p), _ptr(rec), _stream()))
+        return rec
+
+    def detect_embeddings(self, img: torch.Tensor, txt: torch.Tensor, cfg: ConsistencyConfig,
+                          use_bank: bool = True) -> torch.Tensor:
+        """Bank search of the text rows -> gather -> consistency; all on the
+        current stream, no host synchronisation."""
+        B, N1, D = txt.shape
+        if use_bank and self.bank_rows > 0:
+            k = max(cfg.search_k, cfg.reference_count)
+            idx, sim, _ = self.bank_search(txt.reshape(B * N1, D), k, cfg.similarity_threshold, want_moments=False)
+            kf = cfg.reference_count
+            feat = self.bank_gather(idx[:, :kf].contiguous())
+            return self.consistency(img, txt, cfg, idx, sim, feat)
+        return self.consistency(img, txt, cfg)
+
+    # ---- building blocks (parity tests / profiling) ----------------------
+    def gemm(self, a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out[j, i] = sum_k a[i, k] b[j, k] (+ bias[i]); a, b bf16."""
+        a = _require_cuda(a, torch.bfloat16, "a")
+        b = _require_cuda(b, torch.bfloat16, "b")
+        I, K = a.shape
+        J = b.shape[0]
+        if out is None:
+            out = torch.empty((J, I), dtype=torch.float32 if epilogue in (0, 3) else torch.bfloat16, device=self.device)
+            if epilogue == 3:
+                out.zero_()
+        if bias is not None:
+            bias = _require_cuda(bias, torch.float32, "bias")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_gemm_bf16(self.handle, _ptr(a), _ptr(b), _ptr(bias), _ptr(out), I, J, K,
+                                               out.shape[1], epilogue, _stream()))
+        return out
+
+    def attention(self, qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool) -> torch.Tensor:
+        qkv = _require_cuda(qkv, torch.bfloat16, "qkv")
+        out = torch.empty((qkv.shape[0], heads * 64), dtype=torch.bfloat16, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_attention(self.handle, _ptr(qkv), _ptr(out), n_seq, seq_len, heads,
+                                               int(causal), _stream()))
+        return out
+
+    def layernorm(self, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        x = _require_cuda(x, torch.float32, "x")
+        g = _require_cuda(g, torch.float32, "g")
+        b = _require_cuda(b, torch.float32, "b")
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_layernorm(self.handle, _ptr(x), _ptr(g), _ptr(b), _ptr(out), x.shape[0],
+                                               x.shape[1], _stream()))
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.tvc_workspace_bytes(self.handle))

@@ -1,0 +1,115 @@
+"""GPU parity of the HIP building blocks, called through the C-ABI
+(``tvc_gemm_bf16``, ``tvc_layernorm``, ``tvc_attention``, ``tvc_cosine_matrix``).
+Floating-point kernels: compared with a plain PyTorch fp32 restatement of the
+same op on the same (bf16-rounded) operands; tolerances stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("I,J,K", [(256, 256, 64), (512, 300, 128), (768, 1000, 640), (100, 77, 64),
+                                   (1024, 514, 1024), (4, 1, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(gpu_engine, I, J, K, epi):
+    a = _rand((I, K), 1, K ** -0.5).to(torch.bfloat16)
+    b = _rand((J, K), 2).to(torch.bfloat16)
+    bias = _rand((I,), 3, 0.1)
+    ref = b.float() @ a.float().t() + bias          # [J, I]
+    dev = "cuda:0"
+    if epi == 3:
+        base = _rand((J, I), 4)
+        out = base.clone().to(dev)
+        gpu_engine.gemm(a.to(dev), b.to(dev), bias.to(dev), 3, out=out)
+        ref = base + ref
+    else:
+        out = gpu_engine.gemm(a.to(dev), b.to(dev), bias.to(dev), epi)
+    if epi == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    got = out.float().cpu()
+    # fp32 accumulate of exact bf16 products: 1e-4 relative to the row scale;
+    # bf16 outputs add one rounding (2^-9 relative)
+    tol = 2e-4 * (1 + ref.abs().max().item()) if epi in (0, 3) else 1e-2 * (1 + ref.abs().max().item())
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < tol
+
+
+def test_gemm_identity_asymmetric(gpu_engine):
+    """A = I with an asymmetric B catches a transposed accumulator map."""
+    K = 256
+    a = torch.eye(K).to(torch.bfloat16)
+    b = (torch.arange(300 * K).reshape(300, K) % 251).float().to(torch.bfloat16)
+    out = gpu_engine.gemm(a.cuda(), b.cuda(), None, 0).cpu()
+    assert torch.equal(out, b.float())
+
+
+@pytest.mark.parametrize("rows,d", [(5, 128), (1000, 256), (257, 768), (514, 1024)])
+def test_layernorm(gpu_engine, rows, d):
+    x = _rand((rows, d), 5, 3.0) + 0.5
+    g = 1 + _rand((d,), 6, 0.1)
+    b = _rand((d,), 7, 0.1)
+    ref = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+    got = gpu_engine.layernorm(x.cuda(), g.cuda(), b.cuda()).float().cpu()
+    # output is bf16: half an ulp of |ref| <= 2^-9 * max
+    assert (got - ref).abs().max().item() < 2 ** -8 * (1 + ref.abs().max().item())
+
+
+def _attn_ref(qkv, n_seq, T, heads, causal):
+    d = heads * 64
+    q, k, v = qkv.float().view(n_seq, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((T, T), float("-inf")).triu(1)
+    o = s.softmax(-1) @ v
+    return o.permute(0, 2, 1, 3).reshape(n_seq * T, d)
+
+
+@pytest.mark.parametrize("n_seq,T,heads,causal", [(3, 17, 4, False), (2, 50, 12, False), (5, 77, 2, True),
+                                                  (4, 77, 8, True), (2, 257, 16, False), (3, 20, 2, True),
+                                                  (1, 1, 1, False), (2, 288, 2, False), (2, 33, 2, True)])
+def test_attention(gpu_engine, n_seq, T, heads, causal):
+    qkv = _rand((n_seq * T, 3 * heads * 64), 8, 1.0).to(torch.bfloat16)
+    ref = _attn_ref(qkv, n_seq, T, heads, causal)
+    got = gpu_engine.attention(qkv.cuda(), n_seq, T, heads, causal).float().cpu()
+    assert torch.isfinite(got).all()
+    # P and O are rounded to bf16: |err| <~ 2^-8 * max|v|
+    assert (got - ref).abs().max().item() < 3e-2
+    assert (got - ref).abs().mean().item() < 3e-3
+
+
+def test_attention_spiky_scores(gpu_engine):
+    """Large score range (one dominant key per query) must not overflow."""
+    n_seq, T, heads = 2, 257, 2
+    qkv = _rand((n_seq * T, 3 * heads * 64), 9, 1.0)
+    qkv[:, :heads * 64] *= 8.0
+    qkv = qkv.to(torch.bfloat16)
+    ref = _attn_ref(qkv, n_seq, T, heads, False)
+    got = gpu_engine.attention(qkv.cuda(), n_seq, T, heads, False).float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 6e-2
+
+
+@pytest.mark.parametrize("N,M,D", [(7, 33, 128), (300, 1000, 512), (48, 20, 768)])
+def test_cosine_matrix(gpu_engine, pkg, N, M, D):
+    import ctypes as C
+    x = _rand((N, D), 10, 2.0)
+    y = _rand((M, D), 11, 0.5)
+    xn = x.double() / x.double().norm(dim=1, keepdim=True)
+    yn = y.double() / y.double().norm(dim=1, keepdim=True)
+    ref = xn @ yn.t()      # src/utils/metrics.py:162-164
+    out = torch.empty((N, M), dtype=torch.float32, device="cuda:0")
+    xd, yd = x.cuda(), y.cuda()
+    rc = gpu_engine.lib.tvc_cosine_matrix(gpu_engine.handle, C.c_void_p(xd.data_ptr()), N, C.c_void_p(yd.data_ptr()),
+                                          M, D, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    # split-bf16 (3 products) + fp32 accumulate: 1e-5 absolute on cosines (bar: 1e-4)
+    assert (out.double().cpu() - ref).abs().max().item() < 1e-5

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- defended queries/sec of the TVC hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic queries with
+inputs resident in HBM: encode B images + B*(N+1) token rows with the HIP CLIP
+towers, exact top-k search of all B*(N+2) embedding rows against the bank,
+per-query consistency scores, records copied to the host.  Default workload =
+BASELINE.json configs[2]: ViT-L/14 bf16, B=512, N=8, 1M-row bank, one GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: queries are data-parallel (encoders replicated, bank replicated per
+GPU, no collective on the data path) -> "scaling": "weak".  Rank 0 prints ONE
+JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--model", default="ViT-L/14")
+    p.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
+    p.add_argument("--variants", type=int, default=8)
+    p.add_argument("--bank-rows", type=int, default=1_000_000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--no-profile-pass", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(pkg, arch, weights, images, tokens, bank_cpu, budget_s):
+    """The oracle (CPU restatement of the reference path, PyTorch-CPU fp32 towers +
+    numpy scores) timed on this box's host cores on a bounded sample of the same
+    workload, de-duplicated schedule (image encoded once per query)."""
+    import numpy as np
+    import torch
+    from oracle import clip_oracle, tvc_oracle
+    vw, tw = weights
+    N1 = tokens.shape[1]
+
+    def one(i):
+        with torch.no_grad():
+            fi = clip_oracle.vision_forward(vw, images[i:i + 1], arch.vision.heads, arch.patch)
+            ft = clip_oracle.text_forward(tw, tokens[i], arch.text.heads)
+        return tvc_oracle.detect_batch(fi.numpy(), ft.numpy()[None], bank_cpu)
+
+    one(0)                      # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    done = 0
+    while done < images.shape[0]:
+        one(done)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, dt
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("multimodal-detection-consistency_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    arch = pkg.get_arch(a.model)
+    B, N, R, D = a.batch, a.variants, a.bank_rows, arch.embed_dim
+    weights = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, weights[0], weights[1], device=str(dev))
+    images = pkg.synth.make_images(B, arch.image_size, seed=1 + rank).to(dev)
+    tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2 + 1000 * rank).to(dev)
+    bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
+    eng.set_bank(bank)
+    cfg = pkg.ConsistencyConfig()
+    k = max(cfg.search_k, cfg.reference_count)
+
+    def step():
+        fi = eng.encode_image(images)
+        ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))
+        rows = torch.cat([fi, ft])                                  # M = B*(N+2) query-side rows
+        idx, sim, _ = eng.bank_search(rows, k, cfg.similarity_threshold, want_moments=False)
+        tidx, tsim = idx[B:], sim[B:]
+        feat = eng.bank_gather(tidx[:, :cfg.reference_count].contiguous())
+        rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, tidx.contiguous(), tsim.contiguous(), feat)
+        return rec.cpu(), idx[:B].cpu()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.bank_status()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rec, _ = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.bank_status()
+    assert torch.isfinite(rec).all()
+
+    roof = None
+    prof = None
+    if not a.no_profile_pass:
+        # separate pass with HIP events around every launch (not part of the timed region)
+        eng.profile_begin()
+        step()
+        prof = eng.profile_end()
+        g = prof["gemm"]
+        achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
+                "traffic": None, "launches_per_step": g["launches"],
+                "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
+
+    if rank == 0:
+        qps = world * B * a.steps / dt
+        flops_q = arch.flops_image() + (N + 1) * arch.flops_text() + 2.0 * (N + 2) * R * D
+        out = {
+            "metric": "defended queries/sec", "value": round(qps, 2), "unit": "queries/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank, "
+                                   f"encode + exact top-{k} bank search + consistency (BASELINE configs[2])",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_query": round(flops_q / 1e9, 2),
+                       "path_tflops": round(qps * flops_q / 1e12, 1)},
+            "roofline": roof,
+        }
+        if prof:
+            out["kernel_ms_per_step"] = {c: round(v["ms"], 2) for c, v in prof.items()}
+            bk = prof["bank"]
+            if bk["ms"] > 0:
+                out["bank_stage"] = {"mfma_tflops": round(bk["work"] / (bk["ms"] * 1e-3) / 1e12, 1),
+                                     "bank_stream_GBps": round(R * D * 2 / (bk["ms"] * 1e-3) / 1e9, 1)}
+        if not a.no_cpu_baseline and world == 1:
+            import numpy as np
+            nq = min(B, 64)
+            bank_cpu = bank.float().cpu().numpy()
+            v, done, secs = cpu_baseline(pkg, arch, weights, images[:nq].cpu(), tokens[:nq].cpu().long(), bank_cpu,
+                                         a.cpu_seconds)
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": f"{done} queries of the same workload in {secs:.1f}s, oracle "
+                                             f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}
+            out["speedup_vs_cpu"] = round(qps / v, 1) if v > 0 else None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

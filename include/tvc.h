@@ -235,6 +235,18 @@ int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev,
                     const float* ref_feat_dev, int32_t ks, int32_t kf,
                     const tvc_consistency_params* params, float* rec_dev, void* stream);
 
+/* ---- in-process kernel timing (HIP events on the launch stream) ------- */
+
+enum { TVC_PROF_GEMM = 0, TVC_PROF_ATTENTION = 1, TVC_PROF_BANK = 2, TVC_PROF_ROWOPS = 3, TVC_PROF_NCAT = 4 };
+
+/* After tvc_profile_begin every kernel launch made through `h` is bracketed by
+ * a pair of hipEvents on its stream.  tvc_profile_end synchronises, then fills
+ * per category (index = TVC_PROF_*): ms[c] = summed kernel time, work[c] =
+ * summed algorithmic FLOPs (GEMM, attention, bank) or bytes (row ops),
+ * launches[c] = number of launches; profiling is switched off again. */
+int tvc_profile_begin(tvc_handle* h);
+int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches);
+
 /* ---- building blocks exported for parity tests and profiling --------- */
 
 /* out[j, i] = sum_k a[i, k] * b[j, k]  (+ bias[i]); a bf16 [I, K] ("weights"),

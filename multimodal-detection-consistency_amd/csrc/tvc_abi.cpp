@@ -27,6 +27,12 @@ struct Buf {
     size_t n = 0;
 };
 
+struct ProfRec {
+    hipEvent_t a, b;
+    int cat;
+    double work;
+};
+
 }  // namespace
 
 struct tvc_handle {
@@ -45,6 +51,8 @@ struct tvc_handle {
     std::string err;
     int max_chunk_images = 512;
     int max_chunk_texts = 4608;
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
 };
 
 namespace {
@@ -81,6 +89,29 @@ int ensure(tvc_handle* h, Slot s, size_t bytes) {
     return TVC_OK;
 }
 
+// RAII bracket: two events around whatever is launched inside the scope
+struct ProfScope {
+    tvc_handle* h; hipStream_t st; ProfRec r; bool on;
+    ProfScope(tvc_handle* h_, hipStream_t st_, int cat, double work) : h(h_), st(st_), on(h_->prof) {
+        if (!on) return;
+        r.cat = cat; r.work = work;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        h->prof_recs.push_back(r);
+    }
+};
+
+double gemm_flops(const GemmLaunch& g) { return 2.0 * g.I * (double)g.J * g.K * g.planes; }
+
+hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st) {
+    ProfScope ps(h, st, TVC_PROF_GEMM, gemm_flops(g));
+    return launch_gemm_bf16(g, st);
+}
+
 bool tower_ok(const tvc_tower_arch& a) {
     return a.width > 0 && a.layers > 0 && a.heads > 0 && a.width == a.heads * 64 && a.width % 64 == 0 &&
            a.width <= 1024 && a.mlp > 0 && a.mlp % 64 == 0;
@@ -98,25 +129,35 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
     uint16_t* MLP = (uint16_t*)h->ws[WS_MLP].p;
     for (int l = 0; l < a.layers; ++l) {
         const tvc_layer_weights& w = lw[l];
-        HIP_TRY(launch_layernorm(X, d, nullptr, w.ln1_g, w.ln1_b, H, rows, d, st));
+        {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 6.0);
+            HIP_TRY(launch_layernorm(X, d, nullptr, w.ln1_g, w.ln1_b, H, rows, d, st));
+        }
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16;
-        HIP_TRY(launch_gemm_bf16(g, st));
-        HIP_TRY(launch_attention(QKV, H, n_seq, seq_len, a.heads, causal, st));
+        HIP_TRY(timed_gemm(h, g, st));
+        {
+            const double fl = 4.0 * n_seq * a.heads * (double)seq_len * seq_len * 64 * (causal ? 0.5 : 1.0);
+            ProfScope ps(h, st, TVC_PROF_ATTENTION, fl);
+            HIP_TRY(launch_attention(QKV, H, n_seq, seq_len, a.heads, causal, st));
+        }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bo; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
-        HIP_TRY(launch_gemm_bf16(g, st));
-        HIP_TRY(launch_layernorm(X, d, nullptr, w.ln2_g, w.ln2_b, H, rows, d, st));
+        HIP_TRY(timed_gemm(h, g, st));
+        {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 6.0);
+            HIP_TRY(launch_layernorm(X, d, nullptr, w.ln2_g, w.ln2_b, H, rows, d, st));
+        }
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16;
-        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(timed_gemm(h, g, st));
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
         g.bias = w.b2; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
-        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(timed_gemm(h, g, st));
     }
     return TVC_OK;
 }
@@ -219,7 +260,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         GemmLaunch g;
         g.A = h->vw.patch_w; g.lda = Kp; g.I = d; g.B = Pm; g.ldb = Kp; g.J = n * P; g.K = Kp;
         g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(timed_gemm(h, g, st));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));
         if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, st))) return rc;
@@ -230,7 +271,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         g = GemmLaunch();
         g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(timed_gemm(h, g, st));
         if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)b0 * m.embed_dim, n, m.embed_dim, st));
     }
     return TVC_OK;
@@ -261,7 +302,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(launch_gemm_bf16(g, st));
+        HIP_TRY(timed_gemm(h, g, st));
         if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)t0 * m.embed_dim, n, m.embed_dim, st));
     }
     return TVC_OK;
@@ -324,7 +365,11 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     L.cand_cnt = (int32_t*)h->ws[WS_CAND_CNT].p; L.mom_part = (float*)h->ws[WS_MOM_PART].p;
     L.overflow = (int32_t*)h->ws[WS_OVERFLOW].p;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
-    HIP_TRY(launch_bank_search(L, st));
+    {
+        const int planes = h->bank_planes == 2 ? 3 : 2;
+        ProfScope ps(h, st, TVC_PROF_BANK, 2.0 * (double)h->R * M * D * planes);
+        HIP_TRY(launch_bank_search(L, st));
+    }
     return TVC_OK;
 }
 
@@ -397,7 +442,7 @@ int tvc_cosine_matrix(tvc_handle* h, const float* x_dev, int32_t N, const float*
     g.a_plane_off[0] = 0; g.a_plane_off[1] = 0; g.a_plane_off[2] = D;
     g.b_plane_off[0] = 0; g.b_plane_off[1] = D; g.b_plane_off[2] = 0;
     g.out = out_dev; g.ldo = M; g.epilogue = TVC_EPI_F32;
-    HIP_TRY(launch_gemm_bf16(g, st));
+    HIP_TRY(timed_gemm(h, g, st));
     return TVC_OK;
 }
 
@@ -423,6 +468,31 @@ int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev, i
                                        rec_dev, tvc_rec_stride(N), (hipStream_t)stream);
     if (st != hipSuccess) return fail(h, st == hipErrorInvalidValue ? TVC_E_INVALID : TVC_E_HIP,
                                       std::string("tvc_consistency: ") + hipGetErrorString(st));
+    return TVC_OK;
+}
+
+int tvc_profile_begin(tvc_handle* h) {
+    if (!h) return TVC_E_INVALID;
+    for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    h->prof_recs.clear();
+    h->prof = true;
+    return TVC_OK;
+}
+
+int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches) {
+    if (!h) return TVC_E_INVALID;
+    if (!ms || !work || !launches) return fail(h, TVC_E_INVALID, "tvc_profile_end: NULL output");
+    h->prof = false;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int c = 0; c < TVC_PROF_NCAT; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
+    for (auto& r : h->prof_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cat >= 0 && r.cat < TVC_PROF_NCAT) {
+            ms[r.cat] += t; work[r.cat] += r.work; launches[r.cat] += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    h->prof_recs.clear();
     return TVC_OK;
 }
 

@@ -1,0 +1,481 @@
+"""Detectors of both reference implementations over the batched HIP path.
+
+* ``AdversarialDetector`` / ``DetectorConfig`` -- ``src/detector.py:172-904``
+  ("src" polarity: high score => adversarial, ``:399``).
+* ``MultiModalDefenseDetector`` / ``DetectionConfig`` / ``ConsistencyChecker`` --
+  ``experiments/defenses/detector.py``, ``consistency_checker.py`` ("exp"
+  polarity: low score => adversarial, ``consistency_checker.py:93``).
+
+The reference encodes the same image N+1 times and synchronises per variant
+(``src/detector.py:461-471``); here a batch of B queries is ONE image encode,
+ONE text encode of B*(N+1) rows, one bank search and one consistency launch.
+The only per-query host work left is what the reference itself keeps on the
+host: the stateful adaptive threshold / confidence of ``ConsistencyChecker``.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .clip import CLIPConfig, CLIPModel
+from .engine import ConsistencyConfig
+from .variants import as_generator
+
+SRC_WEIGHTS = {"text_variants": 0.4, "sd_reference": 0.4, "consistency": 0.2}   # src/detector.py:666-670
+
+
+# ------------------------------------------------------------------ records
+def unpack_records(rec: torch.Tensor, n_variants: int) -> Dict[str, np.ndarray]:
+    """Device record tensor (layout: include/tvc.h) -> host arrays (ONE D2H copy)."""
+    r = rec.detach().cpu().numpy()
+    N = n_variants
+    M = _lib.TVC_REC_MAXREF
+    return {
+        "original_similarity": r[:, 0].astype(np.float64), "variant_mean": r[:, 1].astype(np.float64),
+        "variant_std": r[:, 2].astype(np.float64), "score_text_variants": r[:, 3].astype(np.float64),
+        "score_consistency": r[:, 4].astype(np.float64), "score_src": r[:, 5].astype(np.float64),
+        "retrieval_consistency": r[:, 6].astype(np.float64), "retrieval_std": r[:, 7].astype(np.float64),
+        "n_references": r[:, 8].astype(np.int64), "cross_modal_variance": r[:, 9].astype(np.float64),
+        "overall_exp": r[:, 10].astype(np.float64),
+        "variant_similarities": r[:, 12:12 + N].astype(np.float64),
+        "reference_indices": np.ascontiguousarray(r[:, 12 + N:12 + N + M]).view(np.int32).astype(np.int64),
+        "reference_similarities": r[:, 12 + N + M:12 + N + 2 * M].astype(np.float64),
+    }
+
+
+# ------------------------------------------------------------- src polarity
+@dataclass
+class DetectorConfig:
+    """src/detector.py:172-212 (same field names and defaults)."""
+    clip_model: str = "ViT-B/32"
+    device: str = "cuda"
+    detection_methods: Optional[List[str]] = None
+    use_text_variants: bool = True
+    num_text_variants: int = 5
+    text_similarity_threshold: float = 0.85
+    use_sd_reference: bool = True
+    num_reference_images: int = 3
+    reference_similarity_threshold: float = 0.75
+    consistency_threshold: float = 0.8
+    consistency_weight: float = 0.5
+    detection_threshold: float = 0.5
+    adaptive_threshold: bool = True
+    threshold_percentile: float = 95.0
+    score_aggregation: str = "weighted_mean"
+    enable_cache: bool = False            # reference default True; hashing device images forces a D2H copy
+    cache_size: int = 1000
+    batch_size: int = 32
+    strict: bool = True                   # False: swallow errors into neutral results like src/detector.py:428-439
+
+    def __post_init__(self):
+        if self.detection_methods is None:
+            self.detection_methods = ["text_variants", "sd_reference", "consistency"]
+
+
+def aggregate_scores(scores: Dict[str, float], method: str = "weighted_mean") -> float:
+    """src/detector.py:643-682."""
+    if not scores:
+        return 0.0
+    vals = list(scores.values())
+    if method == "mean":
+        return float(np.mean(vals))
+    if method == "max":
+        return float(np.max(vals))
+    if method == "min":
+        return float(np.min(vals))
+    if method == "weighted_mean":
+        ws = tw = 0.0
+        for name, s in scores.items():
+            w = SRC_WEIGHTS.get(name, 1.0)
+            ws += s * w
+            tw += w
+        return ws / tw if tw > 0 else 0.0
+    return float(np.mean(vals))
+
+
+class AdversarialDetector:
+    """Drop-in for ``src/detector.py:217`` (``detect_adversarial`` / ``batch_detect``)
+    plus the ``detect`` name the efficiency harness calls
+    (``experiments/run_experiments.py:3253``)."""
+
+    def __init__(self, config: Optional[DetectorConfig] = None, clip_model: Optional[CLIPModel] = None,
+                 text_augmenter=None, sd_generator=None):
+        self.config = config or DetectorConfig()
+        self.clip_model = clip_model
+        self.text_augmenter = text_augmenter
+        self.sd_generator = sd_generator      # object with generate_reference_images(text, num_images) or None
+        self.detection_cache: Dict[str, Dict] = {}
+        self.detection_stats = {"total_detections": 0, "cache_hits": 0, "detection_time": 0.0,
+                                "method_usage": {m: 0 for m in self.config.detection_methods}}
+        self._lock = threading.Lock()
+
+    # -- lazily built components (src/detector.py:253-343) ----------------
+    def _get_clip_model(self) -> CLIPModel:
+        if self.clip_model is None:
+            self.clip_model = CLIPModel(CLIPConfig(model_name=self.config.clip_model, device=self.config.device))
+        return self.clip_model
+
+    def _variants(self, text: str) -> List[str]:
+        if not self.config.use_text_variants:
+            return []
+        return as_generator(self.text_augmenter, self.config.num_text_variants)(text)
+
+    # -- batched core --------------------------------------------------------
+    def detect_tokens(self, images: torch.Tensor, tokens: torch.Tensor) -> Dict[str, np.ndarray]:
+        """images [B,3,S,S], tokens int [B, N+1, ctx] (row 0 = original text) ->
+        host arrays of the record fields (see ``unpack_records``) plus
+        ``aggregated_score`` / ``is_adversarial`` for the methods
+        {text_variants, consistency}."""
+        clip = self._get_clip_model()
+        B, N1, ctx = tokens.shape
+        fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
+        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True)
+        rec = clip.engine.consistency(fi, ft.view(B, N1, -1), ConsistencyConfig())
+        out = unpack_records(rec, N1 - 1)
+        out["aggregated_score"] = out["score_src"]
+        out["is_adversarial"] = out["score_src"] > self.config.detection_threshold      # src/detector.py:399
+        return out
+
+    def batch_detect(self, images, texts: Sequence[str], methods: Optional[List[str]] = None,
+                     variants: Optional[Sequence[Sequence[str]]] = None,
+                     reference_images: Optional[Sequence[Sequence[Any]]] = None) -> List[Dict[str, Any]]:
+        """src/detector.py:711-734, truly batched.  Queries are grouped by their
+        variant count so every group is one launch."""
+        methods = methods or self.config.detection_methods
+        t0 = time.time()
+        clip = self._get_clip_model()
+        if isinstance(images, torch.Tensor) and images.dim() == 3:
+            images = images.unsqueeze(0)
+        n = len(texts)
+        if variants is None:
+            variants = [self._variants(t) if "text_variants" in methods else [] for t in texts]
+        x, _ = clip._images_to_device(images if isinstance(images, torch.Tensor) else list(images))
+        if x.shape[0] != n:
+            raise ValueError("number of images and texts differ")
+        fi = clip.engine.encode_image(x, True)
+        results: List[Optional[Dict[str, Any]]] = [None] * n
+        groups: Dict[int, List[int]] = {}
+        for i, v in enumerate(variants):
+            groups.setdefault(len(v), []).append(i)
+        for N, ids in groups.items():
+            flat = []
+            for i in ids:
+                flat.append(texts[i])
+                flat.extend(variants[i])
+            tok = clip.tokenize(flat)
+            ft = clip.encode_tokens(tok, True).view(len(ids), N + 1, -1)
+            sel = torch.as_tensor(ids, device=fi.device)
+            rec = unpack_records(clip.engine.consistency(fi[sel].contiguous(), ft, ConsistencyConfig()), N)
+            for j, i in enumerate(ids):
+                scores, details = {}, {}
+                if "text_variants" in methods and N > 0:
+                    scores["text_variants"] = float(rec["score_text_variants"][j])
+                    details["text_variants"] = {
+                        "original_similarity": float(rec["original_similarity"][j]),
+                        "variant_similarities": rec["variant_similarities"][j].tolist(),
+                        "mean_variant_similarity": float(rec["variant_mean"][j]),
+                        "std_variant_similarity": float(rec["variant_std"][j]),
+                        "consistency_score": float(1.0 - abs(rec["original_similarity"][j] - rec["variant_mean"][j])),
+                        "variability_score": float(1.0 - rec["variant_std"][j]),
+                        "num_variants": N,
+                    }
+                if "consistency" in methods:
+                    scores["consistency"] = float(rec["score_consistency"][j])
+                    details["consistency"] = {"image_text_similarity": float(rec["original_similarity"][j]),
+                                              "consistency_score": float(rec["original_similarity"][j])}
+                results[i] = {"detection_scores": scores, "detection_details": details}
+        # SD-reference method: arithmetic in scope (src/detector.py:528-553), producing the
+        # reference images is not -- they come from the caller or an injected generator
+        if "sd_reference" in methods:
+            for i in range(n):
+                refs = None
+                if reference_images is not None:
+                    refs = reference_images[i]
+                elif self.sd_generator is not None:
+                    refs = self.sd_generator.generate_reference_images(
+                        texts[i], num_images=self.config.num_reference_images).get("images", [])
+                if refs:
+                    xr, _ = clip._images_to_device(list(refs))
+                    fr = clip.engine.encode_image(xr, True)
+                    r = unpack_records(clip.engine.consistency(fi[i:i + 1], fr.unsqueeze(0), ConsistencyConfig()),
+                                       fr.shape[0] - 1)
+                    sims = np.concatenate([[r["original_similarity"][0]], r["variant_similarities"][0]])
+                    results[i]["detection_scores"]["sd_reference"] = float(1.0 - sims.mean())
+                    results[i]["detection_details"]["sd_reference"] = {
+                        "reference_similarities": sims.tolist(), "mean_similarity": float(sims.mean()),
+                        "max_similarity": float(sims.max()), "std_similarity": float(sims.std()),
+                        "num_references": int(sims.size)}
+        dt = time.time() - t0
+        for res in results:
+            agg = aggregate_scores(res["detection_scores"], self.config.score_aggregation)
+            res.update({"is_adversarial": bool(agg > self.config.detection_threshold),
+                        "aggregated_score": float(agg), "detection_time": dt / max(n, 1),
+                        "methods_used": methods, "threshold": self.config.detection_threshold})
+        with self._lock:
+            self.detection_stats["total_detections"] += n
+            self.detection_stats["detection_time"] += dt
+            for m in methods:
+                if m in self.detection_stats["method_usage"]:
+                    self.detection_stats["method_usage"][m] += n
+        return results
+
+    def detect_adversarial(self, image, text: str, methods: Optional[List[str]] = None, **kw) -> Dict[str, Any]:
+        """src/detector.py:345-439."""
+        methods = methods or self.config.detection_methods
+        try:
+            key = None
+            if self.config.enable_cache:
+                key = self._cache_key(image, text, methods)
+                if key in self.detection_cache:
+                    self.detection_stats["cache_hits"] += 1
+                    return self.detection_cache[key]
+            res = self.batch_detect([image] if not isinstance(image, torch.Tensor) else image, [text], methods, **{
+                k: [v] for k, v in kw.items()})[0]
+            if key is not None:
+                if len(self.detection_cache) >= self.config.cache_size:
+                    del self.detection_cache[next(iter(self.detection_cache))]
+                self.detection_cache[key] = res
+            return res
+        except Exception as e:     # src/detector.py:428-439 swallows; default here is to raise
+            if self.config.strict:
+                raise
+            return {"is_adversarial": False, "aggregated_score": 0.0, "detection_scores": {},
+                    "detection_details": {}, "detection_time": 0.0, "methods_used": methods,
+                    "threshold": self.config.detection_threshold, "error": str(e)}
+
+    detect = detect_adversarial
+
+    @staticmethod
+    def _cache_key(image, text, methods) -> str:
+        """src/detector.py:684-709."""
+        if isinstance(image, torch.Tensor):
+            ih = hash(image.detach().cpu().numpy().tobytes())
+        else:
+            ih = hash(np.array(image).tobytes())
+        return f"{hash(text)}_{ih}_{hash(tuple(sorted(methods)))}"
+
+    def get_detection_stats(self) -> Dict[str, Any]:
+        return dict(self.detection_stats)
+
+
+def create_adversarial_detector(config: Optional[DetectorConfig] = None, **kw) -> AdversarialDetector:
+    """src/detector.py:892."""
+    return AdversarialDetector(config, **kw)
+
+
+# ------------------------------------------------------------- exp polarity
+class ConsistencyChecker:
+    """experiments/defenses/consistency_checker.py:31-272.  Host-side and stateful
+    (``threshold_history``), as in the reference: decisions depend on call order."""
+
+    _NAMES = ("original_similarity", "text_variant_consistency", "retrieval_consistency", "generative_consistency")
+
+    def __init__(self, threshold: float = 0.5, adaptive_threshold: bool = True, voting_strategy: str = "weighted",
+                 weights: Optional[Dict[str, float]] = None):
+        self.base_threshold = threshold
+        self.adaptive_threshold = adaptive_threshold
+        self.voting_strategy = voting_strategy
+        self.weights = weights or {n: 0.25 for n in self._NAMES}
+        self.detection_history: List[Dict] = []
+        self.threshold_history: List[float] = []
+
+    def _compute_overall_score(self, s: Dict[str, float]) -> float:
+        if self.voting_strategy == "simple":
+            v = [s.get(n, 0) for n in self._NAMES if s.get(n, 0) > 0]
+            return float(np.mean(v)) if v else 0.0
+        if self.voting_strategy == "weighted":
+            ws = tw = 0.0
+            for n, w in self.weights.items():
+                if n in s and s[n] > 0:
+                    ws += s[n] * w
+                    tw += w
+            return ws / tw if tw != 0 else 0.0
+        if self.voting_strategy == "adaptive":
+            rel = {"original_similarity": 1.0,
+                   "text_variant_consistency": 1.0 / (1.0 + s.get("text_variant_std", 1.0)),
+                   "retrieval_consistency": 1.0 / (1.0 + s.get("retrieval_std", 1.0)),
+                   "generative_consistency": 1.0 / (1.0 + s.get("generative_std", 1.0))}
+            tot = sum(rel.values())
+            if tot > 0:
+                rel = {k: v / tot for k, v in rel.items()}
+            ws = tw = 0.0
+            for n in self._NAMES:
+                v = s.get(n, 0)
+                if v > 0:
+                    ws += v * rel[n]
+                    tw += rel[n]
+            return ws / tw if tw != 0 else 0.0
+        raise ValueError(f"unknown voting strategy: {self.voting_strategy}")
+
+    def _get_adaptive_threshold(self, s: Dict[str, float]) -> float:
+        thr = self.base_threshold
+        if s.get("cross_modal_variance", 0) > 0.1:
+            thr += 0.1
+        if np.mean([s.get("text_variant_std", 0), s.get("retrieval_std", 0), s.get("generative_std", 0)]) > 0.2:
+            thr += 0.05
+        if len(self.threshold_history) > 10:
+            thr = 0.7 * thr + 0.3 * np.mean(self.threshold_history[-10:])
+        return float(np.clip(thr, 0.1, 0.9))
+
+    def _compute_confidence(self, overall: float, thr: float, s: Dict[str, float]) -> float:
+        dist = abs(overall - thr) / thr
+        v = [s.get(n, 0) for n in self._NAMES if s.get(n, 0) > 0]
+        cons = 1.0 - np.std(v) if len(v) > 1 else 0.5
+        var = 1.0 - min(s.get("cross_modal_variance", 0), 1.0)
+        return float(np.clip(np.mean([dist, cons, var]), 0.0, 1.0))
+
+    def make_decision(self, consistency_scores: Dict[str, float], return_details: bool = False) -> Dict[str, Any]:
+        overall = self._compute_overall_score(consistency_scores)
+        thr = self._get_adaptive_threshold(consistency_scores) if self.adaptive_threshold else self.base_threshold
+        is_adv = overall < thr
+        conf = self._compute_confidence(overall, thr, consistency_scores)
+        self.detection_history.append({"overall_score": overall, "threshold": thr, "is_adversarial": is_adv,
+                                       "confidence": conf})
+        self.threshold_history.append(thr)
+        res = {"is_adversarial": bool(is_adv), "confidence": conf, "overall_score": float(overall),
+               "threshold": float(thr)}
+        if return_details:
+            res["details"] = {"individual_scores": consistency_scores, "overall_score": overall, "threshold": thr}
+        return res
+
+    def reset(self) -> None:
+        self.detection_history.clear()
+        self.threshold_history.clear()
+
+
+@dataclass
+class DetectionConfig:
+    """experiments/defenses/detector.py:20-44."""
+    use_text_variants: bool = True
+    text_variant_count: int = 5
+    use_retrieval_ref: bool = True
+    retrieval_top_k: int = 10
+    retrieval_weight: float = 0.3
+    use_generative_ref: bool = True
+    generation_count: int = 3
+    generation_weight: float = 0.4
+    consistency_threshold: float = 0.5
+    adaptive_threshold: bool = True
+    voting_strategy: str = "weighted"
+    device: str = "cuda"
+    debug_mode: bool = False
+    # retrieval (experiments/defenses/retrieval_ref.py:20-32)
+    reference_count: int = 5
+    similarity_threshold: float = 0.3
+
+
+class MultiModalDefenseDetector:
+    """Drop-in for ``experiments/defenses/detector.py:46``: injected ``clip_model``,
+    optional text-variant generator, bank of reference image features
+    (``features.npy`` rows, already registered on the clip engine with
+    ``set_reference_bank``)."""
+
+    def __init__(self, clip_model: CLIPModel, qwen_model=None, sd_model=None,
+                 config: Optional[DetectionConfig] = None, text_generator=None, retrieval_generator=None):
+        self.clip_model = clip_model
+        self.config = config or DetectionConfig()
+        self.text_variant_generator = text_generator if text_generator is not None else qwen_model
+        self.retrieval_generator = retrieval_generator
+        self.consistency_checker = ConsistencyChecker(threshold=self.config.consistency_threshold,
+                                                      adaptive_threshold=self.config.adaptive_threshold,
+                                                      voting_strategy=self.config.voting_strategy)
+
+    def set_reference_bank(self, features: torch.Tensor) -> None:
+        """features [R, D] L2-normalised (``features.npy``, retrieval_ref.py:99)."""
+        self.clip_model.engine.set_bank(features.to(self.clip_model.device))
+
+    def _cons_cfg(self) -> ConsistencyConfig:
+        c = self.config
+        return ConsistencyConfig(reference_count=c.reference_count, similarity_threshold=c.similarity_threshold,
+                                 retrieval_top_k=c.retrieval_top_k)
+
+    def _variants(self, text: str) -> List[str]:
+        if not self.config.use_text_variants:
+            return []
+        return as_generator(self.text_variant_generator, self.config.text_variant_count)(text)
+
+    def scores_from_tokens(self, images: torch.Tensor, tokens: torch.Tensor) -> Dict[str, np.ndarray]:
+        """Batched core on pre-tokenised input: images [B,3,S,S], tokens [B,N+1,ctx]."""
+        clip = self.clip_model
+        B, N1, ctx = tokens.shape
+        fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
+        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True)
+        use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
+        rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank)
+        if use_bank:
+            clip.engine.bank_status()
+        return unpack_records(rec, N1 - 1)
+
+    @staticmethod
+    def _score_dict(rec: Dict[str, np.ndarray], j: int, has_variants: bool) -> Dict[str, float]:
+        s0 = float(rec["original_similarity"][j])
+        return {
+            "original_similarity": s0,
+            "text_variant_consistency": float(rec["variant_mean"][j]) if has_variants else s0,
+            "text_variant_std": float(rec["variant_std"][j]) if has_variants else 0.0,
+            "retrieval_consistency": float(rec["retrieval_consistency"][j]),
+            "retrieval_std": float(rec["retrieval_std"][j]),
+            "generative_consistency": 0.0, "generative_std": 0.0,       # generation out of scope
+            "cross_modal_variance": float(rec["cross_modal_variance"][j]),
+        }
+
+    def batch_detect(self, images: torch.Tensor, texts: Sequence[str], return_details: bool = False,
+                     variants: Optional[Sequence[Sequence[str]]] = None) -> List[Dict[str, Any]]:
+        """experiments/defenses/detector.py:327-351, batched; decisions are taken
+        in input order (the checker is stateful)."""
+        clip = self.clip_model
+        n = len(texts)
+        if variants is None:
+            variants = [self._variants(t) for t in texts]
+        x, _ = clip._images_to_device(images)
+        fi = clip.engine.encode_image(x, True)
+        per_query: List[Optional[Dict[str, float]]] = [None] * n
+        extra: List[Optional[Dict]] = [None] * n
+        groups: Dict[int, List[int]] = {}
+        for i, v in enumerate(variants):
+            groups.setdefault(len(v), []).append(i)
+        use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
+        for N, ids in groups.items():
+            flat = []
+            for i in ids:
+                flat.append(texts[i])
+                flat.extend(variants[i])
+            ft = clip.encode_tokens(clip.tokenize(flat), True).view(len(ids), N + 1, -1)
+            sel = torch.as_tensor(ids, device=fi.device)
+            rec = unpack_records(clip.engine.detect_embeddings(fi[sel].contiguous(), ft, self._cons_cfg(), use_bank), N)
+            for j, i in enumerate(ids):
+                per_query[i] = self._score_dict(rec, j, N > 0)
+                k = int(rec["n_references"][j])
+                extra[i] = {"retrieval_references": rec["reference_indices"][j, :k].tolist(),
+                            "retrieval_similarities": rec["reference_similarities"][j, :k].tolist()}
+        if use_bank:
+            clip.engine.bank_status()
+        out = []
+        for i in range(n):
+            d = self.consistency_checker.make_decision(per_query[i], return_details=return_details)
+            res = {"is_adversarial": d["is_adversarial"], "confidence": d["confidence"],
+                   "consistency_score": d["overall_score"]}
+            if return_details:
+                res["details"] = {"text_variants": [texts[i]] + list(variants[i]),
+                                  "retrieval_references": extra[i]["retrieval_references"],
+                                  "retrieval_similarities": extra[i]["retrieval_similarities"],
+                                  "generative_references": [], "consistency_scores": per_query[i],
+                                  "detection_details": d}
+            out.append(res)
+        return out
+
+    def detect(self, image: torch.Tensor, text: str, return_details: bool = False, **kw) -> Dict[str, Any]:
+        """experiments/defenses/detector.py:117-170."""
+        return self.batch_detect(image, [text], return_details, **{k: [v] for k, v in kw.items()})[0]
+
+    def get_statistics(self) -> Dict[str, Any]:
+        return {"config": dict(self.config.__dict__),
+                "components": {"text_variant_generator": self.text_variant_generator is not None,
+                               "retrieval_generator": self.clip_model.engine.bank_rows > 0,
+                               "generative_generator": False, "consistency_checker": True}}

@@ -304,5 +304,19 @@ class TVCEngine:
                                                x.shape[1], _stream()))
         return out
 
+    PROF_CATEGORIES = ("gemm", "attention", "bank", "rowops")
+
+    def profile_begin(self) -> None:
+        self._check(self.lib.tvc_profile_begin(self.handle))
+
+    def profile_end(self) -> Dict[str, Dict[str, float]]:
+        """Per kernel category: summed kernel ms (HIP events on the launch stream),
+        summed algorithmic work (FLOPs; bytes for row ops) and launch count."""
+        ms = (C.c_double * 4)()
+        work = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
+        self._check(self.lib.tvc_profile_end(self.handle, ms, work, n))
+        return {c: {"ms": ms[i], "work": work[i], "launches": int(n[i])} for i, c in enumerate(self.PROF_CATEGORIES)}
+
     def workspace_bytes(self) -> int:
         return int(self.lib.tvc_workspace_bytes(self.handle))

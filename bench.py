@@ -126,7 +126,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     eng.bank_status()
-    assert torch.isfinite(rec).all()
+    assert torch.isfinite(rec[:, :11]).all()      # words >= 12+N hold int32 bit patterns (-1 = NaN bits)
 
     roof = None
     prof = None

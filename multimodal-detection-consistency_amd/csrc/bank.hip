@@ -25,7 +25,8 @@
 #include "gemm_core.hpp"
 #include "kernels.hpp"
 
-#define BANK_CAP 64
+#define BANK_CAP 128
+#define BANK_KEFF 16       // tau = max(k, 16)-th largest group maximum: a looser but far less noisy bound
 #define BANK_POOL 6144
 #define BANK_LDS_BYTES (GEMM_LDS_BYTES + 256 * 4 + 2 * 256 * 4 * 4)
 
@@ -42,10 +43,11 @@ void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* 
     if (s < 1) s = 1;
     const int64_t tpc = (nbt + s - 1) / s;
     s = (nbt + tpc - 1) / tpc;
-    // expected survivors per query ~ k * R / n_sample: aim at 16 per chunk list
-    // (cap 64) and at most ~2048 per query (select pool 6144)
-    int64_t ns = (int64_t)k * R / (16 * s);
-    const int64_t ns2 = (int64_t)k * R / 2048;
+    // expected survivors per query ~ keff * R / n_sample (relative spread ~ keff^-1/2):
+    // aim at 8 per chunk list (cap 128) and at most ~2048 per query (select pool 6144)
+    const int keff = k > BANK_KEFF ? k : BANK_KEFF;
+    int64_t ns = (int64_t)keff * R / (8 * s);
+    const int64_t ns2 = (int64_t)keff * R / 2048;
     if (ns < ns2) ns = ns2;
     if (ns < 4096) ns = 4096;
     if (ns > 65536) ns = 65536;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict_
         const float o = gm[u];
         rank += (o > m) || (o == m && u < t);
     }
-    if (rank == k - 1) {
+    const int keff = k > BANK_KEFF ? k : BANK_KEFF;
+    if (rank == keff - 1) {
         float v = m;
         if (v > -INFINITY) v = v - 1e-6f - 1e-6f * fabsf(v);
         tau[q] = v;

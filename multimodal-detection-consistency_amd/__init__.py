@@ -7,9 +7,19 @@ HIP kernels for gfx950 reached through the C-ABI in ``include/tvc.h``.
 There is no CPU fallback: without ``libtvc_hip.so`` and a GPU every compute call
 raises ``TVCError``.
 """
-from . import _lib, synth
+from . import _lib, sharding, synth
 from ._lib import TVCError, build
 from .arch import ARCHS, ClipArch, Tower, get_arch
+from .clip import CLIPConfig, CLIPModel
+from .detector import (AdversarialDetector, ConsistencyChecker, DetectionConfig, DetectorConfig,
+                       MultiModalDefenseDetector, aggregate_scores, create_adversarial_detector, unpack_records)
 from .engine import ConsistencyConfig, TVCEngine
+from .metrics import DetectionEvaluator, DetectionMetrics, SimilarityCalculator
+from .pipeline import (DefensePipeline, MultiModalDetectionPipeline, PipelineConfig, PipelineProfiler,
+                       PipelineResult, create_defense_pipeline, create_detection_pipeline)
+from .ref_bank import ReferenceBank, ReferenceBankConfig, ReferenceItem, create_reference_bank
+from .retrieval import (MultiModalRetriever, RetrievalConfig, RetrievalRefConfig, RetrievalReferenceGenerator,
+                        create_retriever)
+from .variants import TemplateVariantGenerator
 
-__all__ = ["TVCError", "build", "ARCHS", "ClipArch", "Tower", "get_arch", "ConsistencyConfig", "TVCEngine"]
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,119 @@
+"""Multi-GPU execution of the hot path: one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on ROCm).  Replaces
+``src/utils/multi_gpu_processor.py`` (thread-per-GPU queues ``:49-491``, NCCL
+helpers ``:494-620``) and the single-GPU FAISS index (``src/retrieval.py:111-112``).
+
+Two independent axes:
+
+1. **Query batch (pure data parallel).**  Queries are independent: every rank
+   holds the encoder weights and takes ``B / W`` queries; no collective on the
+   data path.  This is what ``bench.py --gpus N`` runs (weak scaling).
+2. **Bank rows (BASELINE configs[3], 10M rows).**  Rank r owns the contiguous
+   rows ``shard_bounds(R, W, r)``.  Per batch:
+     a. all-gather of the ``[m, D]`` query-side embeddings of every rank
+        (5120 x 768 fp32 = 15.7 MB in total at config 4);
+     b. every rank searches ALL ``W*m`` rows against its shard (exact local
+        top-k with global indices) and gathers the ``kf`` best rows' features;
+     c. all-to-all: rank r receives, for ITS OWN m rows, the W partial lists
+        (``m x k x 8 B`` + ``m x kf x D x 4 B`` per peer: ~10 MB per pair) --
+        xGMI is point-to-point, every link carries a distinct peer's slice;
+     d. ``tvc_topk_merge`` merges the W sorted partials (HIP kernel).
+   The ``[M, R]`` similarity rows are never exchanged.
+
+The collectives move small tensors; all arithmetic stays in the HIP kernels.
+``ShardOps`` is the seam that lets the world_size-2 ``gloo`` CPU test drive the
+same orchestration with a numpy stand-in for the kernels.
+"""
+from __future__ import annotations
+
+from typing import Optional, Protocol, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(R: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range [lo, hi) of ``rank`` (ceil split, last shards may be short)."""
+    per = (R + world - 1) // world
+    lo = min(R, rank * per)
+    return lo, min(R, lo + per)
+
+
+def split_queries(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Query range [lo, hi) of ``rank`` for the data-parallel axis."""
+    return shard_bounds(n, world, rank)
+
+
+class ShardOps(Protocol):
+    def search(self, rows: torch.Tensor, k: int): ...            # -> idx [M,k] (global), sim [M,k]
+    def gather(self, idx: torch.Tensor): ...                      # global idx [M,kf] -> feat [M,kf,D]
+    def merge(self, idx_parts, sim_parts, feat_parts): ...        # [W,M,*] -> idx, sim, feat
+
+
+class HipShardOps:
+    """The product ops: C-ABI kernels on this rank's bank shard."""
+
+    def __init__(self, engine, row_offset: int, count_thr: float = 0.3):
+        self.engine = engine
+        self.row_offset = row_offset
+        self.count_thr = count_thr
+
+    def search(self, rows: torch.Tensor, k: int):
+        idx, sim, _ = self.engine.bank_search(rows, k, self.count_thr, idx_offset=self.row_offset, want_moments=False)
+        return idx, sim
+
+    def gather(self, idx: torch.Tensor):
+        return self.engine.bank_gather(idx.contiguous(), idx_offset=self.row_offset)
+
+    def merge(self, idx_parts, sim_parts, feat_parts):
+        idx, sim, feat, _ = self.engine.topk_merge(idx_parts, sim_parts, feat_parts)
+        return idx, sim, feat
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    """inp/out [W, ...]: out[w] = what rank w sent to me.  RCCL: one all_to_all_single;
+    gloo (CPU tests) lacks it for some dtypes -> all_gather + slice."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(out, inp.contiguous(), group=group)
+        return
+    W = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    bufs = [torch.empty_like(inp) for _ in range(W)]
+    dist.all_gather(bufs, inp.contiguous(), group=group)
+    for w in range(W):
+        out[w].copy_(bufs[w][me])
+
+
+class ShardedBankSearch:
+    """Exact global top-k over a row-sharded bank for data-parallel query rows."""
+
+    def __init__(self, ops: ShardOps, group=None):
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def search(self, rows: torch.Tensor, k: int, kf: int):
+        """rows [m, D] (this rank's query-side rows; m equal on every rank) ->
+        idx [m, k] global, sim [m, k], feat [m, kf, D] of the kf best."""
+        W, (m, D) = self.world, rows.shape
+        allrows = torch.empty((W * m, D), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)         # (a)
+        idx, sim = self.ops.search(allrows, k)                                            # (b)
+        feat = self.ops.gather(idx[:, :kf])
+        idx_in = torch.empty((W, m, k), dtype=idx.dtype, device=rows.device)
+        sim_in = torch.empty((W, m, k), dtype=sim.dtype, device=rows.device)
+        feat_in = torch.empty((W, m, kf, D), dtype=feat.dtype, device=rows.device)
+        _all_to_all(idx_in, idx.view(W, m, k), self.group)                                 # (c)
+        _all_to_all(sim_in, sim.view(W, m, k), self.group)
+        _all_to_all(feat_in, feat.view(W, m, kf, D), self.group)
+        return self.ops.merge(idx_in, sim_in, feat_in)                                    # (d)
+
+
+def detect_sharded(engine, search: ShardedBankSearch, img: torch.Tensor, txt: torch.Tensor, cfg) -> torch.Tensor:
+    """Bank-sharded variant of ``TVCEngine.detect_embeddings`` for this rank's B
+    queries: img [B, D], txt [B, N+1, D] -> records [B, rec_stride]."""
+    B, N1, D = txt.shape
+    k = max(cfg.search_k, cfg.reference_count)
+    idx, sim, feat = search.search(txt.reshape(B * N1, D), k, cfg.reference_count)
+    return engine.consistency(img, txt, cfg, idx, sim, feat)

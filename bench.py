@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-profile-pass", action="store_true")
+    p.add_argument("--dense-text", action="store_true",
+                   help="run the text tower on all 77 positions (disable EOT packing)")
     return p.parse_args()
 
 
@@ -94,12 +96,14 @@ def main():
     tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2 + 1000 * rank).to(dev)
     bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
     eng.set_bank(bank)
+    if a.dense_text:
+        eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
     cfg = pkg.ConsistencyConfig()
     k = max(cfg.search_k, cfg.reference_count)
 
     def step():
-        fi = eng.encode_image(images)
-        ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))
+        ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))   # first: its one row-count read-back
+        fi = eng.encode_image(images)                               # happens while the GPU is still idle
         rows = torch.cat([fi, ft])                                  # M = B*(N+2) query-side rows
         idx, sim, _ = eng.bank_search(rows, k, cfg.similarity_threshold, want_moments=False)
         tidx, tsim = idx[B:], sim[B:]

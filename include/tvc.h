@@ -113,6 +113,17 @@ void tvc_destroy(tvc_handle* h);
  * h == NULL).  Never NULL. */
 const char* tvc_last_error(tvc_handle* h);
 
+/* Options.  TVC_OPT_TEXT_PACKING (default 1): the text tower processes only the
+ * tokens up to and including EOT of every text (ragged, packed rows).  Under the
+ * causal mask later positions cannot influence the pooled EOT row, so the output
+ * is bit-identical to the dense [T, ctx] computation while the work drops by
+ * ctx / mean length.  With packing on, tvc_encode_text synchronises `stream`
+ * once per call (it reads back the packed row count that sizes the GEMM grids).
+ * TVC_OPT_MAX_CHUNK_IMAGES / _TEXTS: rows of a batch processed per pass
+ * (workspace bound; defaults 512 / 4608). */
+enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3 };
+int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
+
 /* Bytes of device workspace currently held by the handle. */
 uint64_t tvc_workspace_bytes(tvc_handle* h);
 

@@ -18,6 +18,7 @@ HEADER_PATH = PKG_DIR.parent / "include" / "tvc.h"
 TVC_OK, TVC_E_INVALID, TVC_E_HIP, TVC_E_NOMEM, TVC_E_STATE, TVC_E_OVERFLOW = range(6)
 TVC_DTYPE_BF16, TVC_DTYPE_F32 = 0, 1
 TVC_REC_HEAD, TVC_REC_MAXREF = 12, 16
+TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS = 1, 2, 3
 
 
 class TVCError(RuntimeError):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "tvc_destroy": (None, [_P]),
     "tvc_last_error": (C.c_char_p, [_P]),
     "tvc_workspace_bytes": (C.c_uint64, [_P]),
+    "tvc_set_option": (C.c_int, [_P, C.c_int32, C.c_int64]),
     "tvc_encode_image": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_encode_text": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_bank_set": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),

@@ -22,37 +22,52 @@
 #define ATT_KROW 128     // K image: 64 bf16 per row
 #define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
 
-template <int MAXT, bool CAUSAL>
+template <int MAXT, bool CAUSAL, int WPS>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv,
-                                                        uint16_t* __restrict__ out, int T, int heads) {
+                                                        uint16_t* __restrict__ out,
+                                                        const int32_t* __restrict__ starts, int T_fixed,
+                                                        int heads, int n_items, int k_bytes, int region_bytes) {
+    // WPS waves cooperate on one (sequence, head) item; a workgroup holds 4 / WPS items,
+    // each with its own K/V region in LDS.  Short text sequences use WPS = 1.
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IPW = 4 / WPS;
     const int width = heads * ATT_DH;
-    const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
-    const int64_t row0 = (int64_t)seq * T;
-    const int NT = (T + 15) >> 4;          // key tiles of 16
-    const int NP = (NT + 1) >> 1;          // key pairs of 32
-    const int KT = NT * 16, VT = NP * 32;
-    char* ldsK = smem;
-    char* ldsV = smem + KT * ATT_KROW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int item_local = wave / WPS, wsub = wave - item_local * WPS;
+    int item = blockIdx.x * IPW + item_local;
+    const bool active = item < n_items;
+    if (!active) item = n_items - 1;
+    const int seq = item / heads, h = item - seq * heads;
+    int64_t row0;
+    int T;
+    if (starts) { row0 = starts[seq]; T = starts[seq + 1] - starts[seq]; }
+    else { row0 = (int64_t)seq * T_fixed; T = T_fixed; }
+    if (T > MAXT * 16) T = MAXT * 16;      // host guarantees this; never index past the region
+    const int NT = (T + 15) >> 4;          // key tiles of 16
+    const int NP = (NT + 1) >> 1;          // key pairs of 32
+    const int KT = NT * 16, VT = NP * 32;
+    char* ldsK = smem + item_local * region_bytes;
+    char* ldsV = ldsK + k_bytes;
     const int64_t ld = 3 * (int64_t)width;
+    const int tsub = wsub * 64 + lane;     // thread index within the item's waves
 
     // ---- fill K / V images (zero beyond T) --------------------------------
-    for (int idx = tid; idx < KT * 8; idx += 256) {
+    for (int idx = tsub; idx < KT * 8; idx += WPS * 64) {
         const int key = idx >> 3, c = idx & 7;
         u32x4_t v = {0u, 0u, 0u, 0u};
         if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + width + h * ATT_DH + c * 8);
         *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = v;
     }
-    for (int idx = tid; idx < VT * 8; idx += 256) {
+    for (int idx = tsub; idx < VT * 8; idx += WPS * 64) {
         const int key = idx >> 3, c = idx & 7;
         u32x4_t v = {0u, 0u, 0u, 0u};
         if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + 2 * width + h * ATT_DH + c * 8);
         *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = v;
     }
     __syncthreads();
+    if (!active) return;
 
     const int g = lane >> 4, r16 = lane & 15;
     const int sw0 = ((0 + g) ^ ((lane >> 1) & 7)) << 4;
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // dh^-0.5 * log2(e)
     const int NQ = NT;
 
-    for (int qb = wave; qb < NQ; qb += 4) {
+    for (int qb = wsub; qb < NQ; qb += WPS) {
         const int qr = qb * 16 + r16;
         const int qrc = qr < T ? qr : T - 1;
         const uint16_t* qp = qkv + (row0 + qrc) * ld + h * ATT_DH + 8 * g;
@@ -157,35 +172,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     }
 }
 
-template <int MAXT, bool CAUSAL>
-static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, int n_seq, int T, int heads,
-                             hipStream_t stream) {
-    const int NT = (T + 15) / 16, NP = (NT + 1) / 2;
-    const size_t lds = (size_t)NT * 16 * ATT_KROW + (size_t)NP * 32 * ATT_VROW;
+template <int MAXT, bool CAUSAL, int WPS>
+static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
+                             int max_T, int heads, hipStream_t stream) {
+    const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
+    const int k_bytes = NT * 16 * ATT_KROW;
+    const int region = k_bytes + NP * 32 * ATT_VROW;
+    constexpr int IPW = 4 / WPS;
+    const size_t lds = (size_t)region * IPW;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (st != hipSuccess) return st;
         attr_done = true;
     }
-    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL>), dim3(n_seq * heads), dim3(256), lds, stream,
-                       qkv, out, T, heads);
+    const int n_items = n_seq * heads;
+    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS>), dim3((n_items + IPW - 1) / IPW), dim3(256), lds, stream,
+                       qkv, out, starts, T, heads, n_items, k_bytes, region);
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, int n_seq, int seq_len, int heads,
-                            int causal, hipStream_t stream) {
+// starts == nullptr: n_seq sequences of seq_len rows each; otherwise sequence s owns rows
+// [starts[s], starts[s+1]) (device array of n_seq + 1 ints) and seq_len is the MAXIMUM length.
+hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len,
+                            int heads, int causal, hipStream_t stream) {
     if (n_seq <= 0) return hipSuccess;
     if (seq_len < 1 || seq_len > 288 || heads < 1) return hipErrorInvalidValue;
     const int NT = (seq_len + 15) / 16;
     if (causal) {
-        if (NT <= 2) return launch_one<2, true>(qkv, out, n_seq, seq_len, heads, stream);
-        if (NT <= 6) return launch_one<6, true>(qkv, out, n_seq, seq_len, heads, stream);
-        return launch_one<18, true>(qkv, out, n_seq, seq_len, heads, stream);
+        if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+        if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+        return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
     }
-    if (NT <= 2) return launch_one<2, false>(qkv, out, n_seq, seq_len, heads, stream);
-    if (NT <= 4) return launch_one<4, false>(qkv, out, n_seq, seq_len, heads, stream);
-    if (NT <= 6) return launch_one<6, false>(qkv, out, n_seq, seq_len, heads, stream);
-    return launch_one<18, false>(qkv, out, n_seq, seq_len, heads, stream);
+    if (NT <= 2) return launch_one<2, false, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+    if (NT <= 4) return launch_one<4, false, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+    if (NT <= 6) return launch_one<6, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+    return launch_one<18, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
 }

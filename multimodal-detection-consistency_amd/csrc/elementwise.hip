@@ -197,27 +197,85 @@ hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const
 }
 
 // ---------------------------------------------------------------------------
-// text embedding: x[n, t, :] = tok_emb[tok[n, t], :] + pos[t, :];
-// eot_row[n] = n*ctx + argmax_t tok[n, t]  (first maximum, as torch.argmax)
+// text lengths: len[n] = argmax_t tok[n, t] + 1 (tokens up to and including EOT;
+// later positions cannot influence the pooled output under the causal mask);
+// starts = exclusive scan, starts[n_text] = total rows, starts[n_text+1] = max len.
+// One workgroup; n_text is a few thousand.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __restrict__ tok,
+                                                               int32_t* __restrict__ starts, int n_text, int ctx) {
+    __shared__ int part[1024];
+    __shared__ int carry_s;
+    __shared__ int maxlen_s;
+    const int t = threadIdx.x;
+    if (t == 0) { carry_s = 0; maxlen_s = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_text; base += 1024) {
+        const int n = base + t;
+        int len = 0;
+        if (n < n_text) {
+            int best = -1, best_t = 0;
+            for (int tt = 0; tt < ctx; ++tt) {
+                const int v = tok[(int64_t)n * ctx + tt];
+                if (v > best) { best = v; best_t = tt; }
+            }
+            len = best_t + 1;
+            atomicMax(&maxlen_s, len);
+        }
+        part[t] = len;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = (t >= o) ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        const int carry = carry_s;
+        if (n < n_text) starts[n] = carry + part[t] - len;
+        __syncthreads();
+        if (t == 1023) carry_s = carry + part[1023];
+        __syncthreads();
+    }
+    if (t == 0) { starts[n_text] = carry_s; starts[n_text + 1] = maxlen_s; }
+}
+
+hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int n_text, int ctx, hipStream_t stream) {
+    hipLaunchKernelGGL(text_lens_scan_kernel, dim3(1), dim3(1024), 0, stream, tok, starts, n_text, ctx);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// text embedding: x[row(n, t), :] = tok_emb[tok[n, t], :] + pos[t, :];
+// eot_row[n] = row of the arg-max id (first maximum, as torch.argmax).
+// Dense rows (starts == nullptr): row = n*ctx + t.  Packed rows: row =
+// starts[n] + t for t < len[n] only.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tok,
                                                          const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos,
                                                          float* __restrict__ x,
-                                                         int32_t* __restrict__ eot_row, int n_text,
+                                                         int32_t* __restrict__ eot_row,
+                                                         const int32_t* __restrict__ starts, int n_text,
                                                          int ctx, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= (int64_t)n_text * ctx) return;
     const int t = (int)(row % ctx);
     const int64_t n = row / ctx;
+    int64_t out_row = row;
+    if (starts) {
+        const int s0 = starts[n], len = starts[n + 1] - s0;
+        if (t >= len) return;
+        out_row = s0 + t;
+        if (t == 0 && lane == 0) eot_row[n] = s0 + len - 1;
+    }
     int id = tok[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const f32x4_t* er = (const f32x4_t*)(tok_emb + (int64_t)id * d);
     const f32x4_t* pr = (const f32x4_t*)(pos + (int64_t)t * d);
-    f32x4_t* xr = (f32x4_t*)(x + row * d);
+    f32x4_t* xr = (f32x4_t*)(x + out_row * d);
     for (int c = lane; c < (d >> 2); c += 64) xr[c] = er[c] + pr[c];
-    if (t == 0) {
+    if (t == 0 && !starts) {
         // arg-max over the ctx ids of text n; ties -> lowest position
         int best = -1, best_t = 0;
         for (int tt = lane; tt < ctx; tt += 64) {
@@ -235,13 +293,14 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
 }
 
 hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
-                             int32_t* eot_row, int n_text, int ctx, int d, int vocab,
+                             int32_t* eot_row, const int32_t* starts, int n_text, int ctx, int d, int vocab,
                              hipStream_t stream) {
     if (d % 4 != 0) return hipErrorInvalidValue;
     const int64_t rows = (int64_t)n_text * ctx;
     if (rows == 0) return hipSuccess;
     const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(text_embed_kernel, dim3(grid), dim3(256), 0, stream, tok, tok_emb, pos, x, eot_row, n_text, ctx, d, vocab);
+    hipLaunchKernelGGL(text_embed_kernel, dim3(grid), dim3(256), 0, stream, tok, tok_emb, pos, x, eot_row, starts,
+                       n_text, ctx, d, vocab);
     return hipGetLastError();
 }
 

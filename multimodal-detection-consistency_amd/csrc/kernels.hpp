@@ -30,9 +30,14 @@ hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int 
 hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
                                  const float* g, const float* b, float* x, int B, int T, int d,
                                  hipStream_t stream);
+// starts == nullptr: dense [n_text, ctx] rows; else packed rows (text n owns rows
+// [starts[n], starts[n+1]), i.e. its tokens up to and including EOT)
 hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
-                             int32_t* eot_row, int n_text, int ctx, int d, int vocab,
+                             int32_t* eot_row, const int32_t* starts, int n_text, int ctx, int d, int vocab,
                              hipStream_t stream);
+// starts[0..n_text] = exclusive scan of (argmax position + 1); starts[n_text + 1] = max length
+hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int n_text, int ctx,
+                                 hipStream_t stream);
 hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream);
 hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
                                hipStream_t stream);
@@ -41,8 +46,8 @@ hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int 
                               hipStream_t stream);
 
 // ---- attention.hip
-hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, int n_seq, int seq_len, int heads,
-                            int causal, hipStream_t stream);
+hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq,
+                            int seq_len, int heads, int causal, hipStream_t stream);
 
 // ---- bank.hip
 struct BankSearchLaunch {

@@ -16,7 +16,7 @@ namespace {
 thread_local std::string g_create_error;
 
 enum Slot {
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT,
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT, WS_STARTS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
     WS_COUNT
@@ -51,6 +51,7 @@ struct tvc_handle {
     std::string err;
     int max_chunk_images = 512;
     int max_chunk_texts = 4608;
+    bool pack_text = true;     // TVC_OPT_TEXT_PACKING
     bool prof = false;
     std::vector<ProfRec> prof_recs;
 };
@@ -118,11 +119,12 @@ bool tower_ok(const tvc_tower_arch& a) {
 }
 
 // One transformer tower over `rows` packed token rows (n_seq sequences of seq_len).
+// Sequences: n_seq x seq_len dense rows, or (starts != nullptr) packed rows with
+// `total_rows` rows in all and seq_len = the maximum length.
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
-               int causal, hipStream_t st) {
+               int causal, const int32_t* starts, int total_rows, hipStream_t st) {
     const int d = a.width;
-    const int64_t rows64 = (int64_t)n_seq * seq_len;
-    const int rows = (int)rows64;
+    const int rows = starts ? total_rows : n_seq * seq_len;
     float* X = (float*)h->ws[WS_X].p;
     uint16_t* H = (uint16_t*)h->ws[WS_H].p;
     uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
@@ -138,9 +140,10 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16;
         HIP_TRY(timed_gemm(h, g, st));
         {
-            const double fl = 4.0 * n_seq * a.heads * (double)seq_len * seq_len * 64 * (causal ? 0.5 : 1.0);
+            const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
+            const double fl = 4.0 * n_seq * a.heads * avg_len * avg_len * 64 * (causal ? 0.5 : 1.0);
             ProfScope ps(h, st, TVC_PROF_ATTENTION, fl);
-            HIP_TRY(launch_attention(QKV, H, n_seq, seq_len, a.heads, causal, st));
+            HIP_TRY(launch_attention(QKV, H, starts, n_seq, seq_len, a.heads, causal, st));
         }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -263,7 +266,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         HIP_TRY(timed_gemm(h, g, st));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));
-        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, st))) return rc;
+        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, st))) return rc;
         // ln_post on the class rows, projection, L2 norm
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
         HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, h->vw.ln_post_g,
@@ -291,12 +294,30 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk))) return rc;
     if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
+    if ((rc = ensure(h, WS_STARTS, (size_t)(chunk + 2) * 4))) return rc;
     for (int t0 = 0; t0 < Tn; t0 += chunk) {
         const int n = (Tn - t0 < chunk) ? Tn - t0 : chunk;
         int32_t* eot = (int32_t*)h->ws[WS_EOT].p;
-        HIP_TRY(launch_text_embed(tok_dev + (size_t)t0 * ctx, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_X].p, eot,
-                                  n, ctx, d, m.vocab, st));
-        if ((rc = run_layers(h, a, h->tw.layers, n, ctx, 1, st))) return rc;
+        const int32_t* tok = tok_dev + (size_t)t0 * ctx;
+        const int32_t* starts = nullptr;
+        int total_rows = n * ctx, max_len = ctx;
+        if (h->pack_text) {
+            // Keep only the tokens up to and including EOT: under the causal mask the later
+            // positions cannot reach the pooled (EOT) row, so the result is bit-identical.
+            // The row count sizes the GEMM grids, hence ONE 8-byte read-back per call.
+            int32_t* sd = (int32_t*)h->ws[WS_STARTS].p;
+            HIP_TRY(launch_text_lens_scan(tok, sd, n, ctx, st));
+            int32_t tail[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(tail, sd + n, sizeof tail, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            total_rows = tail[0]; max_len = tail[1];
+            if (total_rows < n || total_rows > n * ctx || max_len < 1 || max_len > ctx)
+                return fail(h, TVC_E_HIP, "tvc_encode_text: inconsistent sequence lengths");
+            starts = sd;
+        }
+        HIP_TRY(launch_text_embed(tok, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_X].p, eot, starts, n, ctx, d,
+                                  m.vocab, st));
+        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, st))) return rc;
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
         HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, d, eot, h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
         GemmLaunch g;
@@ -471,6 +492,20 @@ int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev, i
     return TVC_OK;
 }
 
+int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
+    if (!h) return TVC_E_INVALID;
+    switch (option) {
+        case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
+        case TVC_OPT_MAX_CHUNK_IMAGES:
+            if (value < 1) return fail(h, TVC_E_INVALID, "tvc_set_option: chunk must be >= 1");
+            h->max_chunk_images = (int)value; return TVC_OK;
+        case TVC_OPT_MAX_CHUNK_TEXTS:
+            if (value < 1) return fail(h, TVC_E_INVALID, "tvc_set_option: chunk must be >= 1");
+            h->max_chunk_texts = (int)value; return TVC_OK;
+        default: return fail(h, TVC_E_INVALID, "tvc_set_option: unknown option");
+    }
+}
+
 int tvc_profile_begin(tvc_handle* h) {
     if (!h) return TVC_E_INVALID;
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -513,7 +548,7 @@ int tvc_attention(tvc_handle* h, const uint16_t* qkv_dev, uint16_t* out_dev, int
                   int32_t heads, int32_t causal, void* stream) {
     if (!h) return TVC_E_INVALID;
     if (!qkv_dev || !out_dev) return fail(h, TVC_E_INVALID, "tvc_attention: NULL buffer");
-    HIP_TRY(launch_attention(qkv_dev, out_dev, n_seq, seq_len, heads, causal, (hipStream_t)stream));
+    HIP_TRY(launch_attention(qkv_dev, out_dev, nullptr, n_seq, seq_len, heads, causal, (hipStream_t)stream));
     return TVC_OK;
 }
 

@@ -318,5 +318,9 @@ class TVCEngine:
         self._check(self.lib.tvc_profile_end(self.handle, ms, work, n))
         return {c: {"ms": ms[i], "work": work[i], "launches": int(n[i])} for i, c in enumerate(self.PROF_CATEGORIES)}
 
+    def set_option(self, option: int, value: int) -> None:
+        """``_lib.TVC_OPT_*`` (e.g. text packing on / off)."""
+        self._check(self.lib.tvc_set_option(self.handle, option, value))
+
     def workspace_bytes(self) -> int:
         return int(self.lib.tvc_workspace_bytes(self.handle))

@@ -168,3 +168,24 @@ def test_towers_vs_oracle(pkg):
         ri2 = clip_oracle.vision_forward(vr, imgs, arch.vision.heads, arch.patch, normalize=False)
     assert (gi2 - ri2).abs().max().item() < 2e-2 * ri2.abs().max().item()
     eng.close()
+
+
+def test_text_packing_is_bit_identical(pkg):
+    """TVC_OPT_TEXT_PACKING drops the tokens after EOT; under the causal mask the
+    pooled row cannot depend on them, so packed == dense bit for bit."""
+    arch = pkg.get_arch("ViT-T/16-test")
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, None, tw)
+    toks = pkg.synth.make_tokens(40, 2, arch.ctx, seed=5, min_len=1, max_len=75).reshape(-1, arch.ctx)
+    toks[3, :] = 0; toks[3, 0] = 49406; toks[3, 1] = 49407                 # shortest legal text
+    toks[5, 1:76] = 17; toks[5, 76] = 49407                                 # longest: EOT at position 76
+    packed = eng.encode_text(toks.cuda()).cpu()
+    eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
+    dense = eng.encode_text(toks.cuda()).cpu()
+    assert torch.equal(packed, dense)
+    # junk after EOT must not matter either
+    toks2 = toks.clone()
+    toks2[0, toks[0].argmax() + 1:] = 123
+    eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 1)
+    assert torch.equal(eng.encode_text(toks2.cuda()).cpu()[0], packed[0])
+    eng.close()

@@ -12,7 +12,7 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC_DIR = PKG_DIR / "csrc"
-LIB_PATH = PKG_DIR / "libtvc_hip.so"
+LIB_PATH = Path(os.environ["TVC_LIB_PATH"]) if os.environ.get("TVC_LIB_PATH") else PKG_DIR / "libtvc_hip.so"   # override: kernel experiments only
 HEADER_PATH = PKG_DIR.parent / "include" / "tvc.h"
 
 TVC_OK, TVC_E_INVALID, TVC_E_HIP, TVC_E_NOMEM, TVC_E_STATE, TVC_E_OVERFLOW = range(6)

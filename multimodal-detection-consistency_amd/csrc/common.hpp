@@ -47,6 +47,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same copy issued from inline asm: scalar 64-bit base + per-lane 32-bit byte offset,
+// LDS destination byte address in M0 (saved / restored: M0 is compiler-reserved).
+// hipcc does not count this load in its own vmcnt bookkeeping, so (unlike the builtin)
+// it never drains the queue before a ds_read that "may alias" a pending LDS-DMA:
+// ALL ordering of these loads is by the caller's explicit s_waitcnt vmcnt(N) + barrier.
+// Compiler-counted waits for its own younger loads stay correct (they are only stricter).
+__device__ __forceinline__ void glds16_asm(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+
 // Bijective XCD-contiguous remap of a 1-D grid (8 XCDs, round-robin dispatch):
 // workgroups that land on one XCD get a contiguous range of `lin`, so tiles
 // sharing an operand panel share that XCD's L2.  Speed only, never correctness.

@@ -9,10 +9,15 @@
 #define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 rows
 
 // ---------------------------------------------------------------------------
-// LayerNorm: fp32 row -> bf16 row (GEMM operand).  d % 4 == 0, d <= 1024.
+// (residual add +) LayerNorm: x fp32 row (+ delta bf16 row) -> bf16 row (GEMM
+// operand).  With `delta` the residual GEMMs stay store-only: the previous
+// projection's output is folded into the fp32 residual stream here, in the same
+// streaming pass that normalises it (x is written back when `write_x`).
+// d % 4 == 0, d <= 1024.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t x_row_stride,
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int64_t x_row_stride,
                                                         const int32_t* __restrict__ row_idx,
+                                                        const uint16_t* __restrict__ delta, int write_x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
                                                         uint16_t* __restrict__ y, int rows, int d) {
@@ -20,7 +25,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t src_row = row_idx ? (int64_t)row_idx[row] : (int64_t)row;
-    const f32x4_t* xr = (const f32x4_t*)(x + src_row * x_row_stride);
+    f32x4_t* xr = (f32x4_t*)(x + src_row * x_row_stride);
+    const u32x2_t* dr = delta ? (const u32x2_t*)(delta + src_row * x_row_stride) : nullptr;   // same [rows, d] element offset as x
     const int nv = d >> 2;
     f32x4_t v[4];
     float s = 0.f;
@@ -30,6 +36,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
             v[i] = xr[c];
+            if (dr) {
+                const u32x2_t dd = dr[c];
+                v[i][0] += __uint_as_float(dd[0] << 16);
+                v[i][1] += __uint_as_float(dd[0] & 0xffff0000u);
+                v[i][2] += __uint_as_float(dd[1] << 16);
+                v[i][3] += __uint_as_float(dd[1] & 0xffff0000u);
+                if (write_x) xr[c] = v[i];
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -65,13 +79,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const int32_t* row_idx,
-                            const float* g, const float* b, uint16_t* y, int rows, int d,
+hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
+                            int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
                             hipStream_t stream) {
     if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, g, b, y, rows, d);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, write_x,
+                       g, b, y, rows, d);
     return hipGetLastError();
 }
 

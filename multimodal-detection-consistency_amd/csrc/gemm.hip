@@ -1,7 +1,8 @@
 // Dense bf16 GEMM with fused epilogues for the CLIP towers (K1/K2) and the
 // bank-search pre-pass.  See gemm_core.hpp for the tiling.
-#include "gemm_core.hpp"
+#include "gemm_ring.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 struct GemmEpilogue {
     const float* bias;     // [I] or nullptr
@@ -54,6 +55,81 @@ __device__ __forceinline__ void gemm_store4(const GemmEpilogue& e, int I, int i,
     }
 }
 
+// Epilogue of one 256 x 256 tile.  Fast path (interior tile, aligned rows): the
+// bias vectors are loaded once up front and, for the residual form, the eight
+// read-modify-write loads of a column block are issued before their stores, so
+// no store waits behind a load's vmcnt.
+// BIAS_LDS: the tile's 256 bias values were staged in LDS (at `bias_lds`) by the persistent
+// kernel.  The fast path (tile fully inside the output, aligned rows) contains no
+// exec-masked region and no global load that is not consumed before its end, so hipcc's
+// waitcnt pass sees nothing pending when a persistent caller loops back.
+template <int EPI, bool BIAS_LDS = false>
+__device__ __forceinline__ void gemm_tile_epilogue(const gemm_acc_t& acc, const GemmOperands& g,
+                                                   const GemmEpilogue& e, int i0, int j0, int wm, int wn, int lane,
+                                                   const char* bias_lds = nullptr) {
+    const bool fast = (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J) && ((e.ldo & 3) == 0);
+    if (fast) {
+        const int il = wm * 128 + (lane >> 4) * 4;          // tile-local first out-feature of this lane
+        auto bias_of = [&](int m) -> f32x4_t {
+            if (!e.bias) return f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (BIAS_LDS)
+                return *(const __attribute__((address_space(3))) f32x4_t*)(
+                    (const __attribute__((address_space(3))) char*)bias_lds + (il + m * 16) * 4);
+            return *(const f32x4_t*)(e.bias + i0 + il + m * 16);
+        };
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int j = j0 + wn * 64 + n * 16 + (lane & 15);
+            if (EPI == TVC_EPI_RESID_F32) {
+                float* p = (float*)e.out + (int64_t)j * e.ldo + i0 + il;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {           // 4 + 4: read-modify-write loads before their stores
+                    f32x4_t r[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) r[m] = *(const f32x4_t*)(p + (h * 4 + m) * 16);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        *(f32x4_t*)(p + (h * 4 + m) * 16) = r[m] + acc[h * 4 + m][n] + bias_of(h * 4 + m);
+                }
+            } else if (EPI == TVC_EPI_F32) {
+                float* p = (float*)e.out + (int64_t)j * e.ldo + i0 + il;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) *(f32x4_t*)(p + m * 16) = acc[m][n] + bias_of(m);
+            } else {
+                uint16_t* p = (uint16_t*)e.out + (int64_t)j * e.ldo + i0 + il;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    f32x4_t v = acc[m][n] + bias_of(m);
+                    if (EPI == TVC_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
+                    }
+                    u32x2_t o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *(u32x2_t*)(p + m * 16) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int j = j0 + wn * 64 + n * 16 + (lane & 15);
+        if (j >= g.J) continue;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = i0 + wm * 128 + m * 16 + (lane >> 4) * 4;
+            if (i < g.I) gemm_store4<EPI>(e, g.I, i, j, acc[m][n]);
+        }
+    }
+    // The loads above sit in exec-masked branches.  Tell hipcc's waitcnt pass that none is
+    // pending when a persistent caller loops back (vmcnt(0), lgkmcnt/expcnt untouched): without
+    // this it guards the loop body's first VGPR write with a vmcnt(0) that drains the LDS-DMA
+    // ring on EVERY stage.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmOperands g, GemmEpilogue e,
                                                                   int nIt, int nJt) {
@@ -68,17 +144,154 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmOperands g,
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    gemm_tile_epilogue<EPI>(acc, g, e, i0, j0, wave >> 2, wave & 3, lane);
+}
+
+
+// ---------------------------------------------------------------------------
+// Persistent ring-pipelined variant (gemm_ring.hpp): used for the big tower GEMMs.
+// ---------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    const int kpp = g.ksteps_per_plane * (GEMM_BK / RING_BK);     // 32-deep stages per plane
+    const int nk = g.planes * kpp;                                 // stages per tile
+
+    RingSchedule sch;
+    sch.init(nIt * nJt);
+    const int my_tiles = sch.count();
+    const int total = my_tiles * nk;                               // stages in this workgroup's stream
+    if (total == 0) return;
+
+    const uint32_t smem_lds = lds_addr(smem);
+    // ---- issue side: scalar tile bases + per-lane 32-bit offsets (recomputed per tile only)
+    int is_tile = 0, is_p = 0, is_kk = 0, is_n = 0;
+    const char* is_abase; const char* is_bbase;
+    uint32_t va[2], vb[2];
+    auto issue_tile = [&](int lin) {
+        const int jt = lin / nIt;
+        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
+        is_abase = (const char*)(g.A + (int64_t)i0 * g.lda);
+        is_bbase = (const char*)(g.B + (int64_t)j0 * g.ldb);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int j = j0 + wn * 64 + n * 16 + (lane & 15);
-        if (j >= g.J) continue;
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 32 + i * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ (3 * ((r >> 3) & 1));
+            int ra = r, rb = r;
+            if (i0 + ra >= g.I) ra = g.I - 1 - i0;
+            if (j0 + rb >= g.J) rb = g.J - 1 - j0;
+            va[i] = (uint32_t)ra * (uint32_t)(g.lda * 2) + c * 16;
+            vb[i] = (uint32_t)rb * (uint32_t)(g.ldb * 2) + c * 16;
+        }
+    };
+    issue_tile(sch.tile(0));
+    auto issue = [&]() {
+        const uint32_t slot = smem_lds + (is_n & (RING_SLOTS - 1)) * RING_SLOT_BYTES + wave * (32 * 64);
+        const char* ab = is_abase + (int64_t)(g.a_plane_off[is_p] + is_kk * RING_BK) * 2;
+        const char* bb = is_bbase + (int64_t)(g.b_plane_off[is_p] + is_kk * RING_BK) * 2;
+        glds16_asm(ab, va[0], slot);
+        glds16_asm(ab, va[1], slot + 16 * 64);
+        glds16_asm(bb, vb[0], slot + RING_HALF_BYTES);
+        glds16_asm(bb, vb[1], slot + RING_HALF_BYTES + 16 * 64);
+        ++is_n;
+        if (++is_kk == kpp) {
+            is_kk = 0;
+            if (++is_p == g.planes) {
+                is_p = 0;
+                if (++is_tile < my_tiles) issue_tile(sch.tile(is_tile));
+            }
+        }
+    };
+
+    // lane-constant fragment read offsets inside a stage
+    const int pos = ((lane >> 4) ^ (3 * ((lane >> 3) & 1))) * 16;
+    const int a_off = (wm * 128 + (lane & 15)) * 64 + pos;
+    const int b_off = RING_HALF_BYTES + (wn * 64 + (lane & 15)) * 64 + pos;
+
+    // ---- ping-pong schedule -------------------------------------------------------------
+    // Waves w and w+4 share a SIMD.  Group 0 (waves 0-3) and group 1 (waves 4-7) run the same
+    // program one barrier apart: while one wave of a SIMD is in its MFMA phase C(y) the other
+    // is in its load phase L(y) (LDS-DMA issue, fragment ds_reads, counted wait), so the
+    // matrix pipe always has a wave feeding it and the load latency of one wave hides behind
+    // its partner's MFMAs.  Barrier interval k: group 0 runs phase k, group 1 phase k-1
+    // (even phases = L, odd = C).
+    //   L(y): issue stage y+3 into slot (y+3)%4 (== slot of stage y-1: both groups finished
+    //         reading it one and two intervals ago); read stage y's fragments; retire OWN pieces
+    //         of stage y+1 (vmcnt(8): stages y+2, y+3 stay in flight) -> barrier.
+    //         Stage y+1 is read by group 0 two intervals later and by group 1 three intervals
+    //         later, after every wave's retire + a barrier.
+    //   C(y): 32 MFMAs on registers (+ the tile epilogue after the last stage) -> barrier.
+    const int gid = wave >> 2;
+    for (int s = 0; s < 3 && s < total; ++s) issue();
+    if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // stage 0 (own pieces)
+    else if (total == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (gid == 1) __builtin_amdgcn_s_barrier();                               // the one-interval stagger
+    asm volatile("" ::: "memory");
+
+    int S = 0;
+    for (int t = 0; t < my_tiles; ++t) {
+        gemm_acc_t acc;
+        gemm_zero_acc(acc);
+        const int lin = sch.tile(t);
+        const int jt = lin / nIt;
+        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
+        for (int ks = 0; ks < nk; ++ks, ++S) {
+            // ---------------- L(S)
+#ifndef TVC_ABL_NO_GLDS
+            if (S + 3 < total) issue();
+#endif
+            if (ks == 0 && wave == 0 && e.bias && i0 + GEMM_BM <= g.I) {
+                // this tile's 256 bias values -> LDS for the epilogue (retired by wave 0's
+                // counted waits: >= 8 stages follow; the previous tile's epilogue of BOTH groups
+                // finished at least one barrier ago)
+                glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES);
+            }
+            const char* slot = smem + (S & (RING_SLOTS - 1)) * RING_SLOT_BYTES;
+            bf16x8_t a[8], b[4];
+#ifndef TVC_ABL_NO_DSREAD
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int i = i0 + wm * 128 + m * 16 + (lane >> 4) * 4;
-            if (i < g.I) gemm_store4<EPI>(e, g.I, i, j, acc[m][n]);
+            for (int m = 0; m < 8; ++m) a[m] = *(const bf16x8_t*)(slot + a_off + m * 1024);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *(const bf16x8_t*)(slot + b_off + n * 1024);
+#else
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { a[m] = __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)(S + m), 1u, 2u, 3u}); asm volatile("" : "+v"(a[m])); }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { b[n] = __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)(S + n), 5u, 6u, 7u}); asm volatile("" : "+v"(b[n])); }
+#endif
+            const int beyond = (S + 3 < total ? S + 3 : total - 1) - S;      // stages issued beyond S
+            if (beyond >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (beyond == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---------------- C(S)
+            __builtin_amdgcn_s_setprio(1);
+#ifndef TVC_ABL_NO_MFMA
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+#else
+#pragma unroll
+            for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(a[m]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(b[n]));
+#endif
+            __builtin_amdgcn_s_setprio(0);
+            if (ks == nk - 1) gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
+    if (gid == 0) __builtin_amdgcn_s_barrier();                               // pairs with group 1's last barrier
 }
 
 static hipError_t set_lds_attr_once() {
@@ -95,6 +308,15 @@ static hipError_t set_lds_attr_once() {
     SET_ATTR(gemm_bf16_kernel<TVC_EPI_GELU_BF16>)
     SET_ATTR(gemm_bf16_kernel<TVC_EPI_RESID_F32>)
 #undef SET_ATTR
+#define SET_ATTR(K)                                                                              \
+    if (st == hipSuccess)                                                                        \
+        st = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                 RING_LDS_BYTES + 1024);
+    SET_ATTR(gemm_ring_kernel<TVC_EPI_F32>)
+    SET_ATTR(gemm_ring_kernel<TVC_EPI_BF16>)
+    SET_ATTR(gemm_ring_kernel<TVC_EPI_GELU_BF16>)
+    SET_ATTR(gemm_ring_kernel<TVC_EPI_RESID_F32>)
+#undef SET_ATTR
     return st;
 }
 
@@ -109,7 +331,34 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     GemmEpilogue e;
     e.bias = L.bias; e.out = L.out; e.ldo = L.ldo;
     const int nIt = (L.I + GEMM_BM - 1) / GEMM_BM, nJt = (L.J + GEMM_BN - 1) / GEMM_BN;
-    const dim3 grid(nIt * nJt), block(GEMM_THREADS);
+    const dim3 block(GEMM_THREADS);
+    // variant: 0 = one tile per workgroup (gemm_core.hpp), 1 = persistent ring (gemm_ring.hpp).
+    // The ring needs enough tiles to keep 256 persistent workgroups busy.
+    static const int forced = [] { const char* v = getenv("TVC_GEMM_VARIANT"); return v ? atoi(v) : -1; }();
+    const int ntiles = nIt * nJt;
+    const bool deep = (int64_t)L.K * L.planes >= 256;      // >= 8 ring stages per tile
+    const bool ring = deep && (forced >= 0 ? (forced == 1 && ntiles >= 8) : (ntiles >= 512));
+    if (ring) {
+        const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles / 8) * 8);
+        switch (L.epilogue) {
+            case TVC_EPI_F32:
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_F32>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                break;
+            case TVC_EPI_BF16:
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_BF16>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                break;
+            case TVC_EPI_GELU_BF16:
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_GELU_BF16>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                break;
+            case TVC_EPI_RESID_F32:
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_RESID_F32>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    const dim3 grid(nIt * nJt);
     switch (L.epilogue) {
         case TVC_EPI_F32:
             hipLaunchKernelGGL(gemm_bf16_kernel<TVC_EPI_F32>, grid, block, GEMM_LDS_BYTES, stream, g, e, nIt, nJt);

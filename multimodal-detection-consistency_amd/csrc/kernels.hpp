@@ -22,8 +22,9 @@ struct GemmLaunch {
 hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 
 // ---- elementwise.hip
-hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const int32_t* row_idx,
-                            const float* g, const float* b, uint16_t* y, int rows, int d,
+// y = LN(x [+ delta]); with delta and write_x the sum is written back to x (residual stream)
+hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
+                            int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
                             hipStream_t stream);
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream);

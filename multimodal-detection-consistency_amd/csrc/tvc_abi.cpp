@@ -16,7 +16,7 @@ namespace {
 thread_local std::string g_create_error;
 
 enum Slot {
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT, WS_STARTS,
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT, WS_STARTS, WS_DELTA,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
     WS_COUNT
@@ -129,11 +129,18 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
     uint16_t* H = (uint16_t*)h->ws[WS_H].p;
     uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
     uint16_t* MLP = (uint16_t*)h->ws[WS_MLP].p;
+    uint16_t* D = (uint16_t*)h->ws[WS_DELTA].p;
+    // The residual projections (attention out-proj, MLP fc2) are store-only GEMMs writing a bf16
+    // `delta`; the NEXT LayerNorm pass folds it into the fp32 residual stream X while it
+    // normalises (one streaming kernel at the HBM roofline instead of a read-modify-write
+    // epilogue inside an MFMA-bound kernel).  The last delta is left pending for the caller's
+    // final LayerNorm (ln_post / ln_final), which receives it through `pending_delta`.
+    const uint16_t* delta = nullptr;
     for (int l = 0; l < a.layers; ++l) {
         const tvc_layer_weights& w = lw[l];
         {
-            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 6.0);
-            HIP_TRY(launch_layernorm(X, d, nullptr, w.ln1_g, w.ln1_b, H, rows, d, st));
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * (delta ? 12.0 : 6.0));
+            HIP_TRY(launch_layernorm(X, d, nullptr, delta, 1, w.ln1_g, w.ln1_b, H, rows, d, st));
         }
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -147,11 +154,11 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.bo; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
+        g.bias = w.bo; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
         HIP_TRY(timed_gemm(h, g, st));
         {
-            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 6.0);
-            HIP_TRY(launch_layernorm(X, d, nullptr, w.ln2_g, w.ln2_b, H, rows, d, st));
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 12.0);
+            HIP_TRY(launch_layernorm(X, d, nullptr, D, 1, w.ln2_g, w.ln2_b, H, rows, d, st));
         }
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -159,8 +166,9 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         HIP_TRY(timed_gemm(h, g, st));
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
-        g.bias = w.b2; g.out = X; g.ldo = d; g.epilogue = TVC_EPI_RESID_F32;
+        g.bias = w.b2; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
         HIP_TRY(timed_gemm(h, g, st));
+        delta = D;
     }
     return TVC_OK;
 }
@@ -172,6 +180,7 @@ int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_
     if ((rc = ensure(h, WS_QKV, (size_t)rows * a.width * 3 * 2))) return rc;
     if ((rc = ensure(h, WS_MLP, (size_t)rows * a.mlp * 2))) return rc;
     if ((rc = ensure(h, WS_CLS, (size_t)n_seq * a.width * 2))) return rc;
+    if ((rc = ensure(h, WS_DELTA, (size_t)rows * a.width * 2))) return rc;
     return TVC_OK;
 }
 
@@ -269,8 +278,9 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, st))) return rc;
         // ln_post on the class rows, projection, L2 norm
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
-        HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, h->vw.ln_post_g,
-                                 h->vw.ln_post_b, Hc, n, d, st));
+        // ln_post on the class rows (row b*T), folding in the last layer's pending fc2 delta
+        HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr,
+                                 (const uint16_t*)h->ws[WS_DELTA].p, 0, h->vw.ln_post_g, h->vw.ln_post_b, Hc, n, d, st));
         g = GemmLaunch();
         g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
@@ -319,7 +329,8 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
                                   m.vocab, st));
         if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, st))) return rc;
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
-        HIP_TRY(launch_layernorm((const float*)h->ws[WS_X].p, d, eot, h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
+        HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, d, eot, (const uint16_t*)h->ws[WS_DELTA].p, 0,
+                                 h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
@@ -556,7 +567,8 @@ int tvc_layernorm(tvc_handle* h, const float* x_dev, const float* g_dev, const f
                   int32_t rows, int32_t d, void* stream) {
     if (!h) return TVC_E_INVALID;
     if (!x_dev || !g_dev || !b_dev || !y_dev) return fail(h, TVC_E_INVALID, "tvc_layernorm: NULL buffer");
-    HIP_TRY(launch_layernorm(x_dev, d, nullptr, g_dev, b_dev, y_dev, rows, d, (hipStream_t)stream));
+    HIP_TRY(launch_layernorm(const_cast<float*>(x_dev), d, nullptr, nullptr, 0, g_dev, b_dev, y_dev, rows, d,
+                             (hipStream_t)stream));
     return TVC_OK;
 }
 

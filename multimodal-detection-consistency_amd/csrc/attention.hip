@@ -23,7 +23,7 @@
 #define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
 
 template <int MAXT, bool CAUSAL, int WPS>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv,
                                                         uint16_t* __restrict__ out,
                                                         const int32_t* __restrict__ starts, int T_fixed,
                                                         int heads, int n_items, int k_bytes, int region_bytes) {
@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int width = heads * ATT_DH;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // everything below is wave-uniform: keep it in SGPRs so that the per-tile guards are scalar
+    // branches, not exec masks
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int item_local = wave / WPS, wsub = wave - item_local * WPS;
     int item = blockIdx.x * IPW + item_local;
     const bool active = item < n_items;
@@ -42,8 +44,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int seq = item / heads, h = item - seq * heads;
     int64_t row0;
     int T;
-    if (starts) { row0 = starts[seq]; T = starts[seq + 1] - starts[seq]; }
-    else { row0 = (int64_t)seq * T_fixed; T = T_fixed; }
+    if (starts) {
+        const int s0 = __builtin_amdgcn_readfirstlane(starts[seq]);
+        const int s1 = __builtin_amdgcn_readfirstlane(starts[seq + 1]);
+        row0 = s0; T = s1 - s0;
+    } else { row0 = (int64_t)seq * T_fixed; T = T_fixed; }
     if (T > MAXT * 16) T = MAXT * 16;      // host guarantees this; never index past the region
     const int NT = (T + 15) >> 4;          // key tiles of 16
     const int NP = (NT + 1) >> 1;          // key pairs of 32
@@ -53,18 +58,42 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int64_t ld = 3 * (int64_t)width;
     const int tsub = wsub * 64 + lane;     // thread index within the item's waves
 
-    // ---- fill K / V images (zero beyond T) --------------------------------
-    for (int idx = tsub; idx < KT * 8; idx += WPS * 64) {
-        const int key = idx >> 3, c = idx & 7;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + width + h * ATT_DH + c * 8);
-        *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+    // ---- fill K / V images (zero beyond T).  All global loads of an image are issued before
+    // the first LDS write, so the workgroup pays ONE memory latency per image, not one per piece.
+    constexpr int STEP = WPS * 64;
+    constexpr int KIT = (MAXT * 16 * 8 + STEP - 1) / STEP;
+    constexpr int VIT = (((MAXT + 1) / 2) * 32 * 8 + STEP - 1) / STEP;
+    {
+        u32x4_t kv[KIT];
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            kv[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (key < T) kv[i] = *(const u32x4_t*)(qkv + (row0 + key) * ld + width + h * ATT_DH + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            if (idx < KT * 8) *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = kv[i];
+        }
     }
-    for (int idx = tsub; idx < VT * 8; idx += WPS * 64) {
-        const int key = idx >> 3, c = idx & 7;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (key < T) v = *(const u32x4_t*)(qkv + (row0 + key) * ld + 2 * width + h * ATT_DH + c * 8);
-        *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = v;
+    {
+        u32x4_t vv[VIT];
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            vv[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (key < T) vv[i] = *(const u32x4_t*)(qkv + (row0 + key) * ld + 2 * width + h * ATT_DH + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            if (idx < VT * 8) *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = vv[i];
+        }
     }
     __syncthreads();
     if (!active) return;
@@ -77,41 +106,50 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int tr_off = (4 * g + (r16 >> 2)) * ATT_VROW + ((r16 & 3) << 3);
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // dh^-0.5 * log2(e)
     const int NQ = NT;
+    // Masking costs nothing after the MFMA: the accumulator is INITIALISED with 0 or -inf
+    // (-inf + q.k = -inf).  Only the last key tile holds keys >= T.
+    f32x4_t pen_tail;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pen_tail[r] = ((NT - 1) * 16 + 4 * g + r >= T) ? -INFINITY : 0.f;
+
+    // Q fragments come straight from HBM/L2: fetch the NEXT block's while this one computes
+    auto q_ptr = [&](int qb) {
+        int qrow = qb * 16 + r16;
+        qrow = qrow < T ? qrow : T - 1;
+        return qkv + (row0 + qrow) * ld + h * ATT_DH + 8 * g;
+    };
+    bf16x8_t nq0 = {}, nq1 = {};
+    if (wsub < NQ) { const uint16_t* qp = q_ptr(wsub); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
 
     for (int qb = wsub; qb < NQ; qb += WPS) {
         const int qr = qb * 16 + r16;
-        const int qrc = qr < T ? qr : T - 1;
-        const uint16_t* qp = qkv + (row0 + qrc) * ld + h * ATT_DH + 8 * g;
-        const bf16x8_t bq0 = *(const bf16x8_t*)(qp);
-        const bf16x8_t bq1 = *(const bf16x8_t*)(qp + 32);
+        const bf16x8_t bq0 = nq0, bq1 = nq1;
+        if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
         const int nt_q = CAUSAL ? ((qb + 1 < NT) ? qb + 1 : NT) : NT;
 
         f32x4_t s[MAXT];
-        float mx = -INFINITY;
+        float mx = -INFINITY;          // max of the RAW scores (scaling by a positive constant is monotonic)
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (t < nt_q) {
+                f32x4_t c0 = (t == NT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (CAUSAL && t == qb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * 16 + 4 * g + r > qr) c0[r] = -INFINITY;
+                }
                 const char* kr = ldsK + (t * 16 + r16) * ATT_KROW;
                 const bf16x8_t a0 = *(const bf16x8_t*)(kr + sw0);
                 const bf16x8_t a1 = *(const bf16x8_t*)(kr + sw1);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
-                const bool need_mask = (t * 16 + 16 > T) || (CAUSAL && t == qb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[t][r] * scale_log2;
-                    if (need_mask) {
-                        const int key = t * 16 + 4 * g + r;
-                        if (key >= T || (CAUSAL && key > qr)) v = -INFINITY;
-                    }
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, c0, 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, c0, 0, 0, 0);
+                mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale_log2;
 
         float lsum = 0.f;
 #pragma unroll
@@ -119,7 +157,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             if (t < nt_q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[t][r] - mx);
+                    // exp2(s * c - max * c): one FMA + raw v_exp_f32 (args <= 0; -inf -> 0)
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2, -mxs));
                     s[t][r] = p;
                     lsum += p;
                 }

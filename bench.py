@@ -45,6 +45,18 @@ def parse():
     return p.parse_args()
 
 
+def host_cpus() -> int:
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(pkg, arch, weights, images, tokens, bank_cpu, budget_s):
     """The oracle (CPU restatement of the reference path, PyTorch-CPU fp32 towers +
     numpy scores) timed on this box's host cores on a bounded sample of the same
@@ -53,7 +65,7 @@ def cpu_baseline(pkg, arch, weights, images, tokens, bank_cpu, budget_s):
     import torch
     from oracle import clip_oracle, tvc_oracle
     vw, tw = weights
-    N1 = tokens.shape[1]
+    torch.set_num_threads(host_cpus())      # more threads than the cgroup quota only thrash
 
     def one(i):
         with torch.no_grad():
@@ -149,6 +161,11 @@ def main():
     if rank == 0:
         qps = world * B * a.steps / dt
         flops_q = arch.flops_image() + (N + 1) * arch.flops_text() + 2.0 * (N + 2) * R * D
+        # executed MFMA work of one step (the text tower runs on the packed rows only; the bank GEMM
+        # multiplies two bf16 planes per query row)
+        exec_flops = None
+        if prof:
+            exec_flops = prof["gemm"]["work"] + prof["attention"]["work"] + prof["bank"]["work"]
         out = {
             "metric": "defended queries/sec", "value": round(qps, 2), "unit": "queries/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
@@ -157,8 +174,10 @@ def main():
             "config": {"workload": f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank, "
                                    f"encode + exact top-{k} bank search + consistency (BASELINE configs[2])",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "algorithmic_gflop_per_query": round(flops_q / 1e9, 2),
-                       "path_tflops": round(qps * flops_q / 1e12, 1)},
+                       "text_packing": "dense-77" if a.dense_text else "eot-packed (bit-identical, see DESIGN.md)",
+                       "algorithmic_gflop_per_query_dense": round(flops_q / 1e9, 2),
+                       "executed_gflop_per_query": round(exec_flops / B / 1e9, 2) if exec_flops else None,
+                       "executed_path_tflops": round(qps * exec_flops / B / 1e12, 1) if exec_flops else None},
             "roofline": roof,
         }
         if prof:

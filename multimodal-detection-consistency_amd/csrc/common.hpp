@@ -62,6 +62,22 @@ __device__ __forceinline__ void glds16_asm(const void* sbase, uint32_t voff, uin
                  : "memory");
 }
 
+// Four pieces of one ring stage in ONE asm statement: a single M0 save / restore, and the
+// second destination of each operand is the first + `second` bytes.
+__device__ __forceinline__ void glds16x4_asm(const void* abase, uint32_t va0, uint32_t va1, uint32_t a_lds,
+                                             const void* bbase, uint32_t vb0, uint32_t vb1, uint32_t b_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %4\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(va0), "v"(va1), "s"(abase), "s"(bbase), "s"(a_lds), "v"(vb0), "v"(vb1), "s"(b_lds)
+                 : "memory", "scc");
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
 }

@@ -11,8 +11,10 @@ struct GemmEpilogue {
 };
 
 __device__ __forceinline__ float quick_gelu(float x) {
-    // x * sigmoid(1.702 x)
-    return x / (1.0f + __expf(-1.702f * x));
+    // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): v_exp_f32 + v_rcp_f32 (1 ulp each; the
+    // result is rounded to bf16 anyway) instead of an IEEE division.  x -> -inf: 2^(+inf) = inf,
+    // rcp(inf) = 0, x * 0 = -0.
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * x));
 }
 
 // out[j, i..i+3] for one lane: i = 4 consecutive out-features.  The vector
@@ -192,10 +194,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
         const uint32_t slot = smem_lds + (is_n & (RING_SLOTS - 1)) * RING_SLOT_BYTES + wave * (32 * 64);
         const char* ab = is_abase + (int64_t)(g.a_plane_off[is_p] + is_kk * RING_BK) * 2;
         const char* bb = is_bbase + (int64_t)(g.b_plane_off[is_p] + is_kk * RING_BK) * 2;
-        glds16_asm(ab, va[0], slot);
-        glds16_asm(ab, va[1], slot + 16 * 64);
-        glds16_asm(bb, vb[0], slot + RING_HALF_BYTES);
-        glds16_asm(bb, vb[1], slot + RING_HALF_BYTES + 16 * 64);
+        glds16x4_asm(ab, va[0], va[1], slot, bb, vb[0], vb[1], slot + RING_HALF_BYTES);   // 16 rows = 0x400 B apart
         ++is_n;
         if (++is_kk == kpp) {
             is_kk = 0;

@@ -189,3 +189,27 @@ def test_text_packing_is_bit_identical(pkg):
     eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 1)
     assert torch.equal(eng.encode_text(toks2.cuda()).cpu()[0], packed[0])
     eng.close()
+
+
+def test_two_shard_search_equals_full_search(gpu_engine):
+    """The bank-sharded path on one GPU: search each half with its global row offset,
+    gather the winners' rows, merge with tvc_topk_merge -> identical to searching the
+    whole bank (indices, similarities and gathered feature rows)."""
+    R, D, M, k, kf = 6001, 256, 77, 8, 3
+    bank = _unit((R, D), 31).to(torch.bfloat16).cuda()
+    q = _unit((M, D), 32).cuda()
+    gpu_engine.set_bank(bank)
+    fi, fs, _ = gpu_engine.bank_search(q, k, want_moments=False)
+    ff = gpu_engine.bank_gather(fi[:, :kf].contiguous())
+    gpu_engine.bank_status()
+    parts_i, parts_s, parts_f, parts_m = [], [], [], []
+    for lo, hi in ((0, 3000), (3000, R)):
+        gpu_engine.set_bank(bank[lo:hi].contiguous())
+        i, s, m = gpu_engine.bank_search(q, k, 0.05, idx_offset=lo)
+        f = gpu_engine.bank_gather(i[:, :kf].contiguous(), idx_offset=lo)
+        gpu_engine.bank_status()
+        parts_i.append(i); parts_s.append(s); parts_f.append(f); parts_m.append(m)
+    mi, ms, mf, mm = gpu_engine.topk_merge(torch.stack(parts_i), torch.stack(parts_s), torch.stack(parts_f), torch.stack(parts_m))
+    assert torch.equal(mi, fi) and torch.equal(ms, fs) and torch.equal(mf, ff)
+    S = q.double() @ bank.double().t()
+    assert (mm[:, 3].cpu() - (S >= 0.05).sum(1).cpu()).abs().max() <= 1

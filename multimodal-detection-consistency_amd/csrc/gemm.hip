@@ -245,10 +245,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
             if (S + 3 < total) issue();
 #endif
             if (ks == 0 && wave == 0 && e.bias && i0 + GEMM_BM <= g.I) {
-                // this tile's 256 bias values -> LDS for the epilogue (retired by wave 0's
-                // counted waits: >= 8 stages follow; the previous tile's epilogue of BOTH groups
-                // finished at least one barrier ago)
-                glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES);
+                // this tile's 256 bias values -> LDS for the epilogue (retired by wave 0's counted
+                // waits: >= 8 stages follow).  TWO bias slots, alternating per tile: group 1 is still
+                // inside the previous tile's epilogue (reading the other slot) while this is issued.
+                glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (t & 1) * 1024);
             }
             const char* slot = smem + (S & (RING_SLOTS - 1)) * RING_SLOT_BYTES;
             bf16x8_t a[8], b[4];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
             for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(b[n]));
 #endif
             __builtin_amdgcn_s_setprio(0);
-            if (ks == nk - 1) gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES);
+            if (ks == nk - 1) gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES + (t & 1) * 1024);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -310,7 +310,7 @@ static hipError_t set_lds_attr_once() {
 #define SET_ATTR(K)                                                                              \
     if (st == hipSuccess)                                                                        \
         st = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                 RING_LDS_BYTES + 1024);
+                                 RING_LDS_BYTES + 2048);
     SET_ATTR(gemm_ring_kernel<TVC_EPI_F32>)
     SET_ATTR(gemm_ring_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring_kernel<TVC_EPI_GELU_BF16>)
@@ -341,16 +341,16 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles / 8) * 8);
         switch (L.epilogue) {
             case TVC_EPI_F32:
-                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_F32>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_F32>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
                 break;
             case TVC_EPI_BF16:
-                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_BF16>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_BF16>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
                 break;
             case TVC_EPI_GELU_BF16:
-                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_GELU_BF16>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_GELU_BF16>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
                 break;
             case TVC_EPI_RESID_F32:
-                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_RESID_F32>, rgrid, block, RING_LDS_BYTES + 1024, stream, g, e, nIt, nJt);
+                hipLaunchKernelGGL(gemm_ring_kernel<TVC_EPI_RESID_F32>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
                 break;
             default:
                 return hipErrorInvalidValue;

@@ -1,0 +1,89 @@
+"""GPU: BASELINE.json configs[0] run exactly (CLIP ViT-B/32, batch 8, N=4 variants, 1k-row
+bank) through the HIP path vs the CPU oracle (fp32 towers on the same random-init weights,
+reference arithmetic), plus size-independent properties at configs[1] scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle, tvc_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b32(pkg):
+    arch = pkg.get_arch("ViT-B/32")
+    w = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, w[0], w[1])
+    yield arch, w, eng
+    eng.close()
+
+
+def test_config0_vit_b32_vs_cpu_reference_path(pkg, b32):
+    arch, (vw, tw), eng = b32
+    B, N, R = 8, 4, 1000
+    images = pkg.synth.make_images(B, arch.image_size, seed=1)
+    tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2)
+    fi = eng.encode_image(images.cuda())
+    ft = eng.encode_text(tokens.view(-1, arch.ctx).cuda()).view(B, N + 1, -1)
+    with torch.no_grad():
+        ri = clip_oracle.vision_forward(vw, images, arch.vision.heads, arch.patch)
+        rt = clip_oracle.text_forward(tw, tokens.view(-1, arch.ctx).long(), arch.text.heads).view(B, N + 1, -1)
+    # bf16 towers (12 layers) vs the fp32 CPU towers on the SAME fp32 weights
+    assert (fi.cpu() * ri).sum(-1).min().item() > 0.999
+    assert (ft.cpu() * rt).sum(-1).min().item() > 0.999
+    bank = pkg.synth.plant_neighbours(pkg.synth.make_bank(R, arch.embed_dim, seed=7), rt.reshape(-1, arch.embed_dim), per_anchor=2)
+    bank16 = bank.to(torch.bfloat16)
+    eng.set_bank(bank16.cuda())
+    rec = eng.detect_embeddings(fi, ft, pkg.ConsistencyConfig()).cpu().numpy()
+    eng.bank_status()
+    # (1) same embeddings -> reference arithmetic within 1e-4 (the BASELINE bar)
+    same = tvc_oracle.detect_batch(fi.cpu().numpy(), ft.cpu().numpy(), bank16.float().numpy(),
+                                   checker=tvc_oracle.ConsistencyCheckerOracle(adaptive_threshold=False))
+    for col, key in ((0, "original_similarity"), (1, "variant_mean"), (2, "variant_std"), (5, "score_src"),
+                     (6, "retrieval_consistency"), (7, "retrieval_std"), (10, "overall_exp")):
+        assert np.abs(rec[:, col] - same[key]).max() < 1e-4, key
+    # (2) end to end vs the fp32 CPU path: bf16-tower tolerance on the scores
+    ref = tvc_oracle.detect_batch(ri.numpy(), rt.numpy(), bank16.float().numpy(),
+                                  checker=tvc_oracle.ConsistencyCheckerOracle(adaptive_threshold=False))
+    assert np.abs(rec[:, 5] - ref["score_src"]).max() < 5e-3
+    assert np.abs(rec[:, 0] - ref["original_similarity"]).max() < 5e-3
+    assert (same["retrieval_indices"] >= 0).any()
+
+
+def test_config1_scale_properties(pkg, b32):
+    """ViT-B/32, batch 256, N=4, 100k-row bank (configs[1]): determinism, batch-split
+    invariance (a query's record does not depend on its batch mates) and bank-permutation
+    equivariance of the retrieved indices."""
+    arch, (vw, tw), eng = b32
+    B, N, R = 256, 4, 100_000
+    images = pkg.synth.make_images(B, arch.image_size, seed=3).cuda()
+    tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=4).cuda()
+    fi = eng.encode_image(images)
+    ft = eng.encode_text(tokens.view(-1, arch.ctx)).view(B, N + 1, -1)
+    # at this batch the big GEMMs run in the persistent ring kernel: spot-check against the CPU towers
+    with torch.no_grad():
+        ri = clip_oracle.vision_forward(vw, images[-4:].cpu(), arch.vision.heads, arch.patch)
+        rt = clip_oracle.text_forward(tw, tokens[-2:].reshape(-1, arch.ctx).cpu().long(), arch.text.heads)
+    assert (fi[-4:].cpu() * ri).sum(-1).min().item() > 0.999
+    assert (ft[-2:].reshape(-1, arch.embed_dim).cpu() * rt).sum(-1).min().item() > 0.999
+    assert torch.equal(fi, eng.encode_image(images))                       # deterministic
+    half = eng.encode_image(images[100:140])
+    assert torch.equal(half, fi[100:140])                                   # batch-split invariant
+    bank = pkg.synth.make_bank(R, arch.embed_dim, seed=7, device="cuda:0", dtype=torch.bfloat16)
+    rows = ft.reshape(-1, arch.embed_dim)
+    eng.set_bank(bank)
+    i1, s1, m1 = eng.bank_search(rows, 5, 0.1)
+    eng.bank_status()
+    perm = torch.randperm(R, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    eng.set_bank(bank[perm].contiguous())
+    i2, s2, m2 = eng.bank_search(rows, 5, 0.1)
+    eng.bank_status()
+    assert torch.equal(s1, s2)                                              # same multiset of similarities
+    ties = (s1[:, 1:] == s1[:, :-1]).any(1)
+    assert torch.equal(perm[i2.long()][~ties], i1.long()[~ties])            # same rows found
+    assert torch.allclose(m1[:, 2], m2[:, 2]) and torch.equal(m1[:, 3], m2[:, 3])
+    # spot check 16 rows against an fp64 matmul
+    S = rows[:16].double() @ bank.double().t()
+    v, ix = S.topk(5, dim=1)
+    assert (s1[:16].double() - v).abs().max().item() < 1e-5 and torch.equal(i1[:16].long(), ix)

@@ -42,6 +42,21 @@ def test_gemm_epilogues(gpu_engine, I, J, K, epi):
     assert (got - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("I,J,K,epi", [(3072, 12800, 768, 2), (1024, 8200, 256, 1), (2304, 20000, 512, 1)])
+def test_gemm_persistent_many_tiles(gpu_engine, I, J, K, epi):
+    """>= 512 tiles: the persistent ring kernel with several tiles (and several bias slices)
+    per workgroup; every row is checked (a stale bias slot shows up only under this load)."""
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    bias = torch.randn(I, device="cuda:0", generator=g) * 3.0          # large: a wrong bias slice is O(1) wrong
+    out = gpu_engine.gemm(a, b, bias, epi).float()
+    ref = b.float() @ a.float().t() + bias
+    if epi == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    assert (out - ref).abs().max().item() < 1e-2 * (1 + ref.abs().max().item())
+
+
 def test_gemm_identity_asymmetric(gpu_engine):
     """A = I with an asymmetric B catches a transposed accumulator map."""
     K = 256

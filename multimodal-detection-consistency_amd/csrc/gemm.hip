@@ -210,87 +210,106 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     const int a_off = (wm * 128 + (lane & 15)) * 64 + pos;
     const int b_off = RING_HALF_BYTES + (wn * 64 + (lane & 15)) * 64 + pos;
 
-    // ---- ping-pong schedule -------------------------------------------------------------
-    // Waves w and w+4 share a SIMD.  Group 0 (waves 0-3) and group 1 (waves 4-7) run the same
-    // program one barrier apart: while one wave of a SIMD is in its MFMA phase C(y) the other
-    // is in its load phase L(y) (LDS-DMA issue, fragment ds_reads, counted wait), so the
-    // matrix pipe always has a wave feeding it and the load latency of one wave hides behind
-    // its partner's MFMAs.  Barrier interval k: group 0 runs phase k, group 1 phase k-1
-    // (even phases = L, odd = C).
-    //   L(y): issue stage y+3 into slot (y+3)%4 (== slot of stage y-1: both groups finished
-    //         reading it one and two intervals ago); read stage y's fragments; retire OWN pieces
-    //         of stage y+1 (vmcnt(8): stages y+2, y+3 stay in flight) -> barrier.
-    //         Stage y+1 is read by group 0 two intervals later and by group 1 three intervals
-    //         later, after every wave's retire + a barrier.
-    //   C(y): 32 MFMAs on registers (+ the tile epilogue after the last stage) -> barrier.
+    // ---- rotated ping-pong schedule, ONE barrier per stage ----------------------------------
+    // Waves w and w+4 share a SIMD.  Per barrier interval S every wave issues its pieces of
+    // stage S+3, reads stage S's fragments and multiplies one stage, but the two groups run the
+    // phases in opposite order:
+    //     group 0 (waves 0-3):  L(S) then C(S)          load fragments, then 32 MFMAs
+    //     group 1 (waves 4-7):  C(S-1) then L(S)        32 MFMAs on last interval's fragments, then load
+    // so while one wave of a SIMD feeds the matrix pipe its partner issues LDS-DMA / ds_reads,
+    // and the barrier + scalar bookkeeping is paid once per 64 MFMAs of a SIMD.
+    //   RAW  stage S is read in interval S; every wave retired its pieces of stage S (counted
+    //        vmcnt) before the barrier that ended interval S-1.
+    //   WAR  stage S+3 goes to slot (S-1)%4, whose reads (interval S-1, both groups, lgkmcnt(0)
+    //        before the barrier) are complete.
+    //   Flight time of a stage: issued in interval S-3+..., retired at the end of interval S-1.
     const int gid = wave >> 2;
     for (int s = 0; s < 3 && s < total; ++s) issue();
     if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // stage 0 (own pieces)
     else if (total == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (gid == 1) __builtin_amdgcn_s_barrier();                               // the one-interval stagger
     asm volatile("" ::: "memory");
 
-    int S = 0;
-    for (int t = 0; t < my_tiles; ++t) {
-        gemm_acc_t acc;
-        gemm_zero_acc(acc);
+    gemm_acc_t acc;
+    gemm_zero_acc(acc);
+    bf16x8_t a[8], b[4];
+    int credit = 0;              // upcoming waits that still see a fast epilogue's 32 stores in the queue
+    int ct = 0, cks = 0;         // tile / k-stage of the stage the MFMAs of this wave work on
+
+    auto tile_origin = [&](int t, int& i0, int& j0) {
         const int lin = sch.tile(t);
         const int jt = lin / nIt;
-        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
-        for (int ks = 0; ks < nk; ++ks, ++S) {
-            // ---------------- L(S)
-#ifndef TVC_ABL_NO_GLDS
-            if (S + 3 < total) issue();
-#endif
-            if (ks == 0 && wave == 0 && e.bias && i0 + GEMM_BM <= g.I) {
-                // this tile's 256 bias values -> LDS for the epilogue (retired by wave 0's counted
-                // waits: >= 8 stages follow).  TWO bias slots, alternating per tile: group 1 is still
-                // inside the previous tile's epilogue (reading the other slot) while this is issued.
-                glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (t & 1) * 1024);
-            }
-            const char* slot = smem + (S & (RING_SLOTS - 1)) * RING_SLOT_BYTES;
-            bf16x8_t a[8], b[4];
-#ifndef TVC_ABL_NO_DSREAD
+        i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
+    };
+    auto load_frags = [&](int S) {
+        const char* slot = smem + (S & (RING_SLOTS - 1)) * RING_SLOT_BYTES;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a[m] = *(const bf16x8_t*)(slot + a_off + m * 1024);
+        for (int m = 0; m < 8; ++m) a[m] = *(const bf16x8_t*)(slot + a_off + m * 1024);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = *(const bf16x8_t*)(slot + b_off + n * 1024);
-#else
+        for (int n = 0; n < 4; ++n) b[n] = *(const bf16x8_t*)(slot + b_off + n * 1024);
+    };
+    auto mfma_stage = [&]() {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { a[m] = __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)(S + m), 1u, 2u, 3u}); asm volatile("" : "+v"(a[m])); }
+        for (int m = 0; m < 8; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { b[n] = __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)(S + n), 5u, 6u, 7u}); asm volatile("" : "+v"(b[n])); }
-#endif
-            const int beyond = (S + 3 < total ? S + 3 : total - 1) - S;      // stages issued beyond S
-            if (beyond >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if (beyond == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // ---------------- C(S)
-            __builtin_amdgcn_s_setprio(1);
-#ifndef TVC_ABL_NO_MFMA
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
-#else
-#pragma unroll
-            for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(a[m]));
-#pragma unroll
-            for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(b[n]));
-#endif
-            __builtin_amdgcn_s_setprio(0);
-            if (ks == nk - 1) gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES + (t & 1) * 1024);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            for (int n = 0; n < 4; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // after the MFMAs of stage (ct, cks): tile epilogue when it was the tile's last stage
+    auto finish_stage = [&](int credit_after) {
+        if (++cks == nk) {
+            int i0, j0;
+            tile_origin(ct, i0, j0);
+            gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES + (ct & 1) * 1024);
+            gemm_zero_acc(acc);
+            const bool fast = (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J) && ((e.ldo & 3) == 0);
+            credit = fast ? credit_after : 0;
+            cks = 0; ++ct;
         }
+    };
+    auto retire_and_barrier = [&](int S) {
+        const int n_out = (S + 3 < total ? S + 3 : total - 1) - S;           // stages in flight beyond S
+        if (n_out >= 3 && credit > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+        else if (n_out >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (n_out == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (credit > 0) --credit;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    if (gid == 0) {
+        int it = 0, iks = 0;     // tile / k-stage of the stage being loaded (== multiplied) this interval
+        for (int S = 0; S < total; ++S) {
+            if (S + 3 < total) issue();
+            if (iks == 0 && wave == 0 && e.bias) {
+                // the tile's 256 bias values -> one of TWO alternating LDS slots (group 1 may still be
+                // in the previous tile's epilogue, reading the other slot); retired by this wave's
+                // counted waits long before the epilogue (>= 8 stages follow)
+                int i0, j0;
+                tile_origin(it, i0, j0);
+                if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (it & 1) * 1024);
+            }
+            if (++iks == nk) { iks = 0; ++it; }
+            load_frags(S);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfma_stage();
+            finish_stage(3);
+            retire_and_barrier(S);
+        }
+    } else {
+        for (int S = 0; S < total; ++S) {
+            if (S > 0) { mfma_stage(); finish_stage(2); }
+            if (S + 3 < total) issue();
+            load_frags(S);
+            retire_and_barrier(S);
+        }
+        mfma_stage();
+        finish_stage(0);
     }
-    if (gid == 0) __builtin_amdgcn_s_barrier();                               // pairs with group 1's last barrier
 }
 
 static hipError_t set_lds_attr_once() {

@@ -16,7 +16,11 @@ namespace {
 thread_local std::string g_create_error;
 
 enum Slot {
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_PATCH, WS_CLS, WS_EOT, WS_STARTS, WS_DELTA,
+    // tower workspaces exist twice (vision, text: + WS_TOWER_N) so that the two towers can run
+    // concurrently on two streams
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_TOWER_N,
+    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA,
+    WS_PATCH, WS_EOT, WS_STARTS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
     WS_COUNT
@@ -122,14 +126,14 @@ bool tower_ok(const tvc_tower_arch& a) {
 // Sequences: n_seq x seq_len dense rows, or (starts != nullptr) packed rows with
 // `total_rows` rows in all and seq_len = the maximum length.
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
-               int causal, const int32_t* starts, int total_rows, hipStream_t st) {
+               int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st) {
     const int d = a.width;
     const int rows = starts ? total_rows : n_seq * seq_len;
-    float* X = (float*)h->ws[WS_X].p;
-    uint16_t* H = (uint16_t*)h->ws[WS_H].p;
-    uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
-    uint16_t* MLP = (uint16_t*)h->ws[WS_MLP].p;
-    uint16_t* D = (uint16_t*)h->ws[WS_DELTA].p;
+    float* X = (float*)h->ws[WS_X + wso].p;
+    uint16_t* H = (uint16_t*)h->ws[WS_H + wso].p;
+    uint16_t* QKV = (uint16_t*)h->ws[WS_QKV + wso].p;
+    uint16_t* MLP = (uint16_t*)h->ws[WS_MLP + wso].p;
+    uint16_t* D = (uint16_t*)h->ws[WS_DELTA + wso].p;
     // The residual projections (attention out-proj, MLP fc2) are store-only GEMMs writing a bf16
     // `delta`; the NEXT LayerNorm pass folds it into the fp32 residual stream X while it
     // normalises (one streaming kernel at the HBM roofline instead of a read-modify-write
@@ -173,14 +177,14 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
     return TVC_OK;
 }
 
-int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq) {
+int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq, int wso) {
     int rc;
-    if ((rc = ensure(h, WS_X, (size_t)rows * a.width * 4))) return rc;
-    if ((rc = ensure(h, WS_H, (size_t)rows * a.width * 2))) return rc;
-    if ((rc = ensure(h, WS_QKV, (size_t)rows * a.width * 3 * 2))) return rc;
-    if ((rc = ensure(h, WS_MLP, (size_t)rows * a.mlp * 2))) return rc;
-    if ((rc = ensure(h, WS_CLS, (size_t)n_seq * a.width * 2))) return rc;
-    if ((rc = ensure(h, WS_DELTA, (size_t)rows * a.width * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_X + wso), (size_t)rows * a.width * 4))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_H + wso), (size_t)rows * a.width * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_QKV + wso), (size_t)rows * a.width * 3 * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_MLP + wso), (size_t)rows * a.mlp * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_CLS + wso), (size_t)n_seq * a.width * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_DELTA + wso), (size_t)rows * a.width * 2))) return rc;
     return TVC_OK;
 }
 
@@ -260,7 +264,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
     const int chunk = B < h->max_chunk_images ? B : h->max_chunk_images;
     if (B == 0) return TVC_OK;
     int rc;
-    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk))) return rc;
+    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk, 0))) return rc;
     if ((rc = ensure(h, WS_PATCH, (size_t)chunk * P * Kp * 2))) return rc;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int n = (B - b0 < chunk) ? B - b0 : chunk;
@@ -275,7 +279,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         HIP_TRY(timed_gemm(h, g, st));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));
-        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, st))) return rc;
+        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, 0, st))) return rc;
         // ln_post on the class rows, projection, L2 norm
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
         // ln_post on the class rows (row b*T), folding in the last layer's pending fc2 delta
@@ -302,7 +306,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     if (Tn == 0) return TVC_OK;
     const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
     int rc;
-    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk))) return rc;
+    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk, WS_TOWER_N))) return rc;
     if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
     if ((rc = ensure(h, WS_STARTS, (size_t)(chunk + 2) * 4))) return rc;
     for (int t0 = 0; t0 < Tn; t0 += chunk) {
@@ -325,11 +329,11 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
                 return fail(h, TVC_E_HIP, "tvc_encode_text: inconsistent sequence lengths");
             starts = sd;
         }
-        HIP_TRY(launch_text_embed(tok, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_X].p, eot, starts, n, ctx, d,
+        HIP_TRY(launch_text_embed(tok, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_TX].p, eot, starts, n, ctx, d,
                                   m.vocab, st));
-        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, st))) return rc;
-        uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
-        HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, d, eot, (const uint16_t*)h->ws[WS_DELTA].p, 0,
+        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st))) return rc;
+        uint16_t* Hc = (uint16_t*)h->ws[WS_TCLS].p;
+        HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
                                  h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;

@@ -1,32 +1,23 @@
-// Persistent, deeper-pipelined bf16 MFMA GEMM main loop for gfx950.
+// Persistent, ring-pipelined bf16 MFMA GEMM main loop for gfx950 (helpers; the kernel and
+// the full schedule description live in gemm.hip: gemm_ring_kernel).
 //
-// Same tile and wave decomposition as gemm_core.hpp (256 x 256 output tile, 8
-// waves as 2 x 4, 8 x 4 MFMA 16x16x32 tiles per wave) but:
+// Same tile and wave decomposition as gemm_core.hpp (256 x 256 output tile, 8 waves as 2 x 4,
+// 8 x 4 MFMA 16x16x32 tiles per wave) but:
+//   * K advances in stages of 32 through a 4-slot LDS ring (4 x (A 16 KiB + B 16 KiB) = 128 KiB):
+//     a stage is issued three barrier intervals before it is read;
+//   * the waits are COUNTED (`s_waitcnt vmcnt(8)` leaves the two younger stages in flight across
+//     the raw `s_barrier`) and the LDS-DMA is issued from inline asm, so hipcc neither adds its own
+//     vmcnt(0) at the barrier nor drains the queue before a ds_read that "may alias" a pending DMA;
+//   * workgroups are persistent: the stage stream runs across output tiles, so the next tile's
+//     first stages are loading while the current tile's epilogue stores;
+//   * rotated ping-pong: the two waves of a SIMD run {load, MFMA} and {MFMA, load} respectively,
+//     one barrier per stage.
 //
-//   * K advances in stages of 32 through a 4-slot LDS ring (4 x (A 16 KiB + B
-//     16 KiB) = 128 KiB): while stage s is multiplied, stages s+1 and s+2 are
-//     already in flight or landed and stage s+3 is issued -> ~3 stages (~1.5
-//     of the old 64-deep steps) of load latency are covered instead of one;
-//   * the waits are COUNTED (`s_waitcnt vmcnt(8)` leaves the two younger
-//     stages in flight across the barrier; never a drain inside a tile) and the
-//     barrier is the raw `s_barrier`, so hipcc does not add its own vmcnt(0);
-//   * workgroups are persistent: the stage stream runs across output tiles, so
-//     the first stages of the next tile are loading while the epilogue of the
-//     current one stores (the old kernel paid prologue + epilogue per tile with
-//     one workgroup per CU and nothing to overlap them with).
-//
-// LDS stage image: rows of 32 bf16 = 64 B, four 16-B chunks; chunk c of row r
-// is stored at chunk c ^ (3 * ((r >> 3) & 1)).  With that swizzle the 16 lanes a
-// ds_read_b128 services together (rows 0-3,12-15 at chunk g and rows 4-11 at
-// chunk g^1, or the converse) hit 16 distinct 16-B slots of the 256-B bank row.
-// As with global_load_lds the destination is lane-linear, the swizzle is applied
-// to the per-lane SOURCE address and to the fragment read address.
-//
-// Ordering rules used (cdna_hip_programming.md, "Pipelining across barriers"):
-//   RAW  a stage is read only after (own vmcnt wait that retires it) + barrier;
-//   WAR  slot (s+3)%4 == (s-1)%4 is re-filled after the barrier of step s, which
-//        every wave passes only after its stage s-1 fragment reads completed
-//        (explicit lgkmcnt(0) before the barrier).
+// LDS stage image: rows of 32 bf16 = 64 B, four 16-B chunks; chunk c of row r is stored at chunk
+// c ^ (3 * ((r >> 3) & 1)).  With that swizzle the 16 lanes a ds_read_b128 services together
+// (rows 0-3,12-15 at chunk g and rows 4-11 at chunk g^1, or the converse) hit 16 distinct 16-B
+// slots of the 256-B bank row.  The DMA destination is lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address and to the fragment read address.
 #pragma once
 #include "gemm_core.hpp"
 

@@ -173,6 +173,14 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k,
                     int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
                     void* stream);
 
+/* Same contract as tvc_bank_search, computed by brute force (the similarities of up to 64 query
+ * rows at a time are materialised and reduced): the fallback for degenerate banks on which
+ * tvc_bank_status reports TVC_E_OVERFLOW.  Orders of magnitude slower; never overflows. */
+int tvc_bank_search_dense(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k,
+                          float count_thr, int64_t idx_offset,
+                          int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
+                          void* stream);
+
 /* Synchronises `stream` and returns TVC_E_OVERFLOW if the last
  * tvc_bank_search dropped candidates (degenerate banks, e.g. thousands of
  * identical rows); TVC_OK otherwise. */

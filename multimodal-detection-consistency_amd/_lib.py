@@ -75,6 +75,7 @@ SIGNATURES = {
     "tvc_encode_text": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_bank_set": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "tvc_bank_search": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P, _P, _P, _P]),
+    "tvc_bank_search_dense": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P, _P, _P, _P]),
     "tvc_bank_status": (C.c_int, [_P, _P]),
     "tvc_bank_gather": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P]),
     "tvc_topk_merge": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

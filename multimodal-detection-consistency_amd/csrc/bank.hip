@@ -317,6 +317,92 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Dense fallback for degenerate banks (candidate lists overflowed): the similarities of a
+// block of query rows are materialised ([m, R] fp32, m <= 64) by the dense GEMM and every row
+// is reduced by k rounds of block arg-max.  Slow (R reads per round) but unconditional.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void row_topk_kernel(float* __restrict__ sims, int64_t R, int k,
+                                                        float count_thr, int64_t idx_offset,
+                                                        int32_t* __restrict__ topk_idx,
+                                                        float* __restrict__ topk_sim,
+                                                        float* __restrict__ moments) {
+    __shared__ float rv[16];
+    __shared__ int ri[16];
+    __shared__ float rs[16], rq[16], rc[16];
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float* row = sims + (int64_t)q * R;
+    if (moments) {
+        float s = 0.f, s2 = 0.f, c = 0.f;
+        for (int64_t i = t; i < R; i += 1024) { const float v = row[i]; s += v; s2 = fmaf(v, v, s2); c += (v >= count_thr) ? 1.f : 0.f; }
+        s = wave_sum(s); s2 = wave_sum(s2); c = wave_sum(c);
+        if (lane == 0) { rs[wave] = s; rq[wave] = s2; rc[wave] = c; }
+        __syncthreads();
+        if (t == 0) {
+            float a = 0.f, b = 0.f, d = 0.f;
+            for (int w = 0; w < 16; ++w) { a += rs[w]; b += rq[w]; d += rc[w]; }
+            moments[(int64_t)q * 4 + 0] = a; moments[(int64_t)q * 4 + 1] = b; moments[(int64_t)q * 4 + 3] = d;
+        }
+        __syncthreads();
+    }
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        bool has = false;
+        for (int64_t i = t; i < R; i += 1024) {
+            const float v = row[i];
+            if (v != -INFINITY && (!has || v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; has = true; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+        __syncthreads();
+        if (t == 0) {
+            float fv = rv[0]; int fi = ri[0];
+            for (int w = 1; w < 16; ++w)
+                if (ri[w] != 0x7fffffff && (fi == 0x7fffffff || rv[w] > fv || (rv[w] == fv && ri[w] < fi))) { fv = rv[w]; fi = ri[w]; }
+            if (fi != 0x7fffffff) {
+                topk_idx[(int64_t)q * k + r] = (int32_t)(fi + idx_offset);
+                topk_sim[(int64_t)q * k + r] = fv;
+                if (r == 0 && moments) moments[(int64_t)q * 4 + 2] = fv;
+                row[fi] = -INFINITY;      // taken
+            } else {
+                topk_idx[(int64_t)q * k + r] = -1;
+                topk_sim[(int64_t)q * k + r] = -INFINITY;
+                if (r == 0 && moments) moments[(int64_t)q * 4 + 2] = -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_bank_search_dense(const BankSearchLaunch& L, float* sims_ws, int block_rows, hipStream_t stream) {
+    const int D = L.D;
+    const int planes = (L.bank_planes == 2) ? 3 : 2;
+    const int a_off[4] = {0, 0, D, 0};
+    const int b_off[4] = {0, D, 0, 0};
+    for (int m0 = 0; m0 < L.M; m0 += block_rows) {
+        const int m = (L.M - m0 < block_rows) ? L.M - m0 : block_rows;
+        GemmLaunch G;
+        G.A = L.bank; G.lda = L.ldb; G.I = (int)L.R;
+        G.B = L.qplanes + (int64_t)m0 * 2 * D; G.ldb = 2 * (int64_t)D; G.J = m; G.K = D; G.planes = planes;
+        for (int p = 0; p < 4; ++p) { G.a_plane_off[p] = a_off[p]; G.b_plane_off[p] = b_off[p]; }
+        G.out = sims_ws; G.ldo = L.R; G.epilogue = TVC_EPI_F32;
+        hipError_t st = launch_gemm_bf16(G, stream);
+        if (st != hipSuccess) return st;
+        hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(1024), 0, stream, sims_ws, L.R, L.k, L.count_thr,
+                           L.idx_offset, L.topk_idx + (int64_t)m0 * L.k, L.topk_sim + (int64_t)m0 * L.k,
+                           L.moments ? L.moments + (int64_t)m0 * 4 : nullptr);
+        st = hipGetLastError();
+        if (st != hipSuccess) return st;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {

@@ -77,6 +77,8 @@ struct BankSearchLaunch {
 };
 void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap);
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream);
+// brute force: sims_ws fp32 [block_rows, R]
+hipError_t launch_bank_search_dense(const BankSearchLaunch& L, float* sims_ws, int block_rows, hipStream_t stream);
 hipError_t launch_topk_merge(const int32_t* idx_parts, const float* sim_parts, const float* feat_parts,
                              const float* mom_parts, int W, int M, int k, int kf, int D,
                              int32_t* idx_out, float* sim_out, float* feat_out, float* mom_out,

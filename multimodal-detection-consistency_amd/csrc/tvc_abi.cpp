@@ -409,6 +409,33 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     return TVC_OK;
 }
 
+int tvc_bank_search_dense(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, float count_thr,
+                          int64_t idx_offset, int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
+                          void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (h->D == 0 || (!h->bank && h->R != 0)) return fail(h, TVC_E_STATE, "tvc_bank_search_dense: call tvc_bank_set first");
+    if (M < 0 || k < 1 || k > 32 || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_bank_search_dense: need 1 <= k <= 32 and non-NULL buffers");
+    if (M == 0) return TVC_OK;
+    if (h->R == 0) return tvc_bank_search(h, rows_dev, M, k, count_thr, idx_offset, topk_idx_dev, topk_sim_dev, moments_dev, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = h->D;
+    int block = (int)((size_t)1 << 28) / (int)(h->R > 0 ? h->R : 1);      // <= 1 GiB of similarities at a time
+    if (block > 64) block = 64;
+    if (block < 1) block = 1;
+    int rc;
+    if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
+    if ((rc = ensure(h, WS_S0, (size_t)block * h->R * 4))) return rc;
+    HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
+    BankSearchLaunch L;
+    L.bank = h->bank; L.ldb = (int64_t)h->bank_planes * D; L.R = h->R; L.D = D; L.bank_planes = h->bank_planes;
+    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
+    L.idx_offset = idx_offset;
+    L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
+    HIP_TRY(launch_bank_search_dense(L, (float*)h->ws[WS_S0].p, block, st));
+    return TVC_OK;
+}
+
 int tvc_bank_status(tvc_handle* h, void* stream) {
     if (!h) return TVC_E_INVALID;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

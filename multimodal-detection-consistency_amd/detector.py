@@ -407,9 +407,7 @@ class MultiModalDefenseDetector:
         fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
         ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True)
         use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
-        rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank)
-        if use_bank:
-            clip.engine.bank_status()
+        rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank, robust=True)
         return unpack_records(rec, N1 - 1)
 
     @staticmethod
@@ -448,14 +446,13 @@ class MultiModalDefenseDetector:
                 flat.extend(variants[i])
             ft = clip.encode_tokens(clip.tokenize(flat), True).view(len(ids), N + 1, -1)
             sel = torch.as_tensor(ids, device=fi.device)
-            rec = unpack_records(clip.engine.detect_embeddings(fi[sel].contiguous(), ft, self._cons_cfg(), use_bank), N)
+            rec = unpack_records(clip.engine.detect_embeddings(fi[sel].contiguous(), ft, self._cons_cfg(), use_bank,
+                                                               robust=True), N)
             for j, i in enumerate(ids):
                 per_query[i] = self._score_dict(rec, j, N > 0)
                 k = int(rec["n_references"][j])
                 extra[i] = {"retrieval_references": rec["reference_indices"][j, :k].tolist(),
                             "retrieval_similarities": rec["reference_similarities"][j, :k].tolist()}
-        if use_bank:
-            clip.engine.bank_status()
         out = []
         for i in range(n):
             d = self.consistency_checker.make_decision(per_query[i], return_details=return_details)

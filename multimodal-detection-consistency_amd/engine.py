@@ -197,6 +197,24 @@ class TVCEngine:
                                                  _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
         return idx, sim, mom
 
+    def bank_search_robust(self, rows: torch.Tensor, k: int, count_thr: float = 0.3, idx_offset: int = 0,
+                           want_moments: bool = True):
+        """``bank_search`` + status check; on candidate overflow (degenerate bank) the same
+        contract is recomputed by the brute-force kernel.  Synchronises the stream."""
+        out = self.bank_search(rows, k, count_thr, idx_offset, want_moments)
+        try:
+            self.bank_status()
+            return out
+        except _lib.TVCError as e:
+            if e.code != _lib.TVC_E_OVERFLOW:
+                raise
+        idx, sim, mom = out
+        rows = _require_cuda(rows, torch.float32, "rows")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_bank_search_dense(self.handle, _ptr(rows), rows.shape[0], k, count_thr, idx_offset,
+                                                       _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
+        return idx, sim, mom
+
     def bank_status(self) -> None:
         """Synchronise and raise ``TVCError(TVC_E_OVERFLOW)`` if the last search dropped candidates."""
         with self._lock, torch.cuda.device(self.device):
@@ -255,13 +273,15 @@ class TVCEngine:
         return rec
 
     def detect_embeddings(self, img: torch.Tensor, txt: torch.Tensor, cfg: ConsistencyConfig,
-                          use_bank: bool = True) -> torch.Tensor:
-        """Bank search of the text rows -> gather -> consistency; all on the
-        current stream, no host synchronisation."""
+                          use_bank: bool = True, robust: bool = False) -> torch.Tensor:
+        """Bank search of the text rows -> gather -> consistency; all on the current stream.
+        ``robust=False``: no host synchronisation, the caller checks ``bank_status()`` later;
+        ``robust=True``: synchronises once and falls back to the brute-force search on overflow."""
         B, N1, D = txt.shape
         if use_bank and self.bank_rows > 0:
             k = max(cfg.search_k, cfg.reference_count)
-            idx, sim, _ = self.bank_search(txt.reshape(B * N1, D), k, cfg.similarity_threshold, want_moments=False)
+            search = self.bank_search_robust if robust else self.bank_search
+            idx, sim, _ = search(txt.reshape(B * N1, D), k, cfg.similarity_threshold, want_moments=False)
             kf = cfg.reference_count
             feat = self.bank_gather(idx[:, :kf].contiguous())
             return self.consistency(img, txt, cfg, idx, sim, feat)

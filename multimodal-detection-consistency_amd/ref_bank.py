@@ -111,8 +111,7 @@ class ReferenceBank:
         if not self.references:
             return False
         self._sync_device()
-        _, sim, _ = self.engine.bank_search(self._query_rows(vector), 1, want_moments=False)
-        self.engine.bank_status()
+        _, sim, _ = self.engine.bank_search_robust(self._query_rows(vector), 1, want_moments=False)
         return bool(sim[0, 0].item() > self.config.similarity_threshold)
 
     def add_reference(self, vector: np.ndarray, metadata: Dict[str, Any]) -> bool:
@@ -161,8 +160,7 @@ class ReferenceBank:
             thr = similarity_threshold or self.config.similarity_threshold       # :191 (0.0 falls through)
             self._sync_device()
             k = max(1, min(top_k, 32))
-            idx, sim, _ = self.engine.bank_search(self._query_rows(query_vector), k, thr, want_moments=False)
-            self.engine.bank_status()
+            idx, sim, _ = self.engine.bank_search_robust(self._query_rows(query_vector), k, thr, want_moments=False)
             idx, sim = idx[0].cpu().numpy(), sim[0].cpu().numpy().astype(np.float64)
             out = []
             for i, s in zip(idx, sim):

@@ -95,8 +95,7 @@ class MultiModalRetriever:
     # -- queries (src/retrieval.py:527-680) ----------------------------------
     def _search(self, q: torch.Tensor, top_k: int) -> Tuple[np.ndarray, np.ndarray]:
         eng = self.clip_model.engine
-        idx, sim, _ = eng.bank_search(q, min(top_k, 32), want_moments=False)
-        eng.bank_status()
+        idx, sim, _ = eng.bank_search_robust(q, min(top_k, 32), want_moments=False)
         idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
         return idx, sim
 
@@ -203,8 +202,7 @@ class RetrievalReferenceGenerator:
         c = self.config
         q = self.clip_model.encode_tokens(self.clip_model.tokenize(list(texts)), True)    # :238-244
         search_k = min(c.rerank_top_k if c.enable_reranking else c.reference_count, eng.bank_rows, 32)   # :249
-        idx, sim, _ = eng.bank_search(q, search_k, c.similarity_threshold, want_moments=False)
-        eng.bank_status()
+        idx, sim, _ = eng.bank_search_robust(q, search_k, c.similarity_threshold, want_moments=False)
         keep = min(c.reference_count, search_k)
         feats = eng.bank_gather(idx[:, :keep].contiguous()).cpu().numpy()
         idx, sim = idx.cpu().numpy(), sim.cpu().numpy()

@@ -84,6 +84,34 @@ def test_bank_search_empty_bank(gpu_engine):
     assert (idx.cpu() == -1).all()
 
 
+def test_bank_search_dense_fallback(gpu_engine, pkg):
+    """Brute-force path: same contract as the fused search, on a normal bank (must agree) and on
+    a degenerate one (40 000 identical rows + a few distinct ones) through bank_search_robust."""
+    D = 128
+    bank = _unit((3000, D), 41).to(torch.bfloat16).cuda()
+    q = _unit((70, D), 42).cuda()
+    gpu_engine.set_bank(bank)
+    i1, s1, m1 = gpu_engine.bank_search(q, 7, 0.05)
+    gpu_engine.bank_status()
+    import ctypes as C
+    i2 = torch.empty_like(i1); s2 = torch.empty_like(s1); m2 = torch.empty_like(m1)
+    rc = gpu_engine.lib.tvc_bank_search_dense(gpu_engine.handle, C.c_void_p(q.data_ptr()), 70, 7, 0.05, 0,
+                                              C.c_void_p(i2.data_ptr()), C.c_void_p(s2.data_ptr()), C.c_void_p(m2.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    assert torch.allclose(m1, m2, rtol=1e-4, atol=1e-3)
+    row = _unit((1, D), 5)
+    degenerate = torch.cat([row.repeat(40000, 1), _unit((50, D), 6)]).to(torch.bfloat16).cuda()
+    gpu_engine.set_bank(degenerate)
+    qq = (row + 0.01 * _unit((3, D), 7)).cuda()
+    qq = qq / qq.norm(dim=-1, keepdim=True)
+    idx, sim, _ = gpu_engine.bank_search_robust(qq, 5)
+    assert idx.cpu().tolist() == [[0, 1, 2, 3, 4]] * 3            # ties -> ascending index
+    S = qq.double() @ degenerate.double().t()
+    assert (sim.double() - S[:, :5]).abs().max().item() < 1e-5
+
+
 def test_bank_search_overflow_is_reported(gpu_engine, pkg):
     """A degenerate bank (all rows identical) cannot be bounded by sampling: the
     overflow must be reported, never silently truncated."""

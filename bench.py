@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-profile-pass", action="store_true")
+    p.add_argument("--shard-bank", action="store_true",
+                   help="BASELINE configs[3]: --bank-rows is the GLOBAL bank, row-sharded over the ranks; "
+                        "partial top-k lists are exchanged with RCCL (all-gather + all-to-all) and merged on the GPU")
     p.add_argument("--serial-towers", action="store_true",
                    help="encode text then images on ONE stream (default: two streams, the towers overlap)")
     p.add_argument("--chunk-images", type=int, default=0, help="images per tower pass (0 = library default)")
@@ -99,9 +102,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.shard_bank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     arch = pkg.get_arch(a.model)
     B, N, R, D = a.batch, a.variants, a.bank_rows, arch.embed_dim
@@ -109,7 +113,12 @@ def main():
     eng = pkg.TVCEngine(arch, weights[0], weights[1], device=str(dev))
     images = pkg.synth.make_images(B, arch.image_size, seed=1 + rank).to(dev)
     tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2 + 1000 * rank).to(dev)
-    bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
+    if a.shard_bank:
+        lo, hi = pkg.sharding.shard_bounds(R, world, rank)
+        bank = pkg.synth.make_bank(hi - lo, D, seed=7 + rank, device=str(dev), dtype=torch.bfloat16)
+        sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3))
+    else:
+        bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
     eng.set_bank(bank)
     if a.dense_text:
         eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
@@ -136,6 +145,12 @@ def main():
                 fi = eng.encode_image(images)
             main.wait_stream(s_txt); main.wait_stream(s_img)
         rows = torch.cat([fi, ft])                                  # M = B*(N+2) query-side rows
+        if a.shard_bank:
+            # every rank searches ALL ranks' rows on its shard; partials go back to the rows' owners
+            idx, sim, feat = sharded.search(rows, k, cfg.reference_count)
+            rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, idx[B:].contiguous(), sim[B:].contiguous(),
+                                  feat[B:].contiguous())
+            return rec.cpu(), idx[:B].cpu()
         idx, sim, _ = eng.bank_search(rows, k, cfg.similarity_threshold, want_moments=False)
         tidx, tsim = idx[B:], sim[B:]
         feat = eng.bank_gather(tidx[:, :cfg.reference_count].contiguous())
@@ -192,7 +207,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank, "
                                    f"encode + exact top-{k} bank search + consistency (BASELINE configs[2])",
-                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "parallelism": (f"dp{world} queries x bank rows sharded {world}-way (RCCL all-gather + all-to-all of partial top-k)"
+                                       if a.shard_bank else f"dp{world}"),
                        "text_packing": "dense-77" if a.dense_text else "eot-packed (bit-identical, see DESIGN.md)",
                        "algorithmic_gflop_per_query_dense": round(flops_q / 1e9, 2),
                        "executed_gflop_per_query": round(exec_flops / B / 1e9, 2) if exec_flops else None,
@@ -217,7 +233,7 @@ def main():
                                              f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}
             out["speedup_vs_cpu"] = round(qps / v, 1) if v > 0 else None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.shard_bank:
         dist.destroy_process_group()
 
 

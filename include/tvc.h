@@ -120,8 +120,15 @@ const char* tvc_last_error(tvc_handle* h);
  * ctx / mean length.  With packing on, tvc_encode_text synchronises `stream`
  * once per call (it reads back the packed row count that sizes the GEMM grids).
  * TVC_OPT_MAX_CHUNK_IMAGES / _TEXTS: rows of a batch processed per pass
- * (workspace bound; defaults 512 / 4608). */
-enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3 };
+ * (workspace bound; defaults 512 / 4608).
+ * TVC_OPT_BANK_FILTER (default 1): when tvc_bank_search is called without a moments
+ * buffer, the bank pass multiplies one bf16 product per element, keeps every row whose
+ * similarity could exceed the running bound (Cauchy-Schwarz margin from the bank's
+ * largest row norms) and re-scores the kept rows in fp32: the same top-k set, values at
+ * least as accurate, 1/2 (bf16 bank) or 1/3 (fp32 bank) of the matrix-core work.  0 forces
+ * the all-products pass. */
+enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
+       TVC_OPT_BANK_FILTER = 4 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
 
 /* Bytes of device workspace currently held by the handle. */

@@ -18,6 +18,13 @@
 //           (~1-2k entries) into LDS and extracts the k best, ordered by
 //           (similarity desc, index asc); reduces the moments over chunks.
 //
+//   fast form (no moments requested): pass 1 multiplies ONE product (bank hi x query hi) and
+//           filters against tau - margin[q], margin = a Cauchy-Schwarz bound of the dropped
+//           products (max bank-row norms x the query's plane norms), so every row whose exact
+//           similarity exceeds tau is still listed; pass 2 re-scores the listed rows in fp32
+//           (bank hi + lo against the fp32 query) before selecting.  Same result set, half /
+//           a third of the MFMA work.
+//
 // Precision: queries are split into bf16 (hi, lo) planes, so with a bf16 bank
 // the products are exact and the result is the fp32-accumulated cosine of the
 // stored values (|err| ~ 1e-6); an fp32 bank is split the same way and uses the
@@ -28,6 +35,7 @@
 #define BANK_CAP 128
 #define BANK_KEFF 16       // tau = max(k, 16)-th largest group maximum: a looser but far less noisy bound
 #define BANK_POOL 6144
+#define BANK_MAX_RESCORE_D 2048   // fp32 query row staged in LDS by the re-scoring select
 #define BANK_LDS_BYTES (GEMM_LDS_BYTES + 256 * 4 + 2 * 256 * 4 * 4)
 
 struct Cand {
@@ -61,10 +69,31 @@ void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* 
 }
 
 // tau[q] = (k-th largest of 256 group maxima of s0[q, :]) minus a safety margin
+// FILTER form: tau is lowered by the bound of what the one-product pass leaves out,
+//   |b.q - bhi.qhi| <= |bhi||qlo| + |blo||qhi| + |blo||qlo|   (bank_bounds = max |bhi|, max |blo|)
 __global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict__ s0, int n_sample,
-                                                        int k, float* __restrict__ tau) {
+                                                        int k, float* __restrict__ tau,
+                                                        const uint16_t* __restrict__ qplanes, int D,
+                                                        const float* __restrict__ bank_bounds) {
     __shared__ float gm[256];
+    __shared__ float nrm[2][4];
     const int q = blockIdx.x, t = threadIdx.x;
+    float margin = 0.f;
+    if (qplanes) {
+        float h2 = 0.f, l2 = 0.f;
+        const uint16_t* qr = qplanes + (int64_t)q * 2 * D;
+        for (int c = t; c < D; c += 256) {
+            const float h = bf16_bits_to_f32(qr[c]), l = bf16_bits_to_f32(qr[D + c]);
+            h2 = fmaf(h, h, h2); l2 = fmaf(l, l, l2);
+        }
+        h2 = wave_sum(h2); l2 = wave_sum(l2);
+        if ((t & 63) == 0) { nrm[0][t >> 6] = h2; nrm[1][t >> 6] = l2; }
+        __syncthreads();
+        const float qh = sqrtf(nrm[0][0] + nrm[0][1] + nrm[0][2] + nrm[0][3]);
+        const float ql = sqrtf(nrm[1][0] + nrm[1][1] + nrm[1][2] + nrm[1][3]);
+        const float bh = bank_bounds[0], bl = bank_bounds[1];
+        margin = (bh * ql + bl * qh + bl * ql) * 1.001f + 4e-6f * (1.f + bh * qh);
+    }
     const float* row = s0 + (int64_t)q * n_sample;
     float m = -INFINITY;
     for (int i = t; i < n_sample; i += 256) m = fmaxf(m, row[i]);
@@ -78,9 +107,59 @@ __global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict_
     const int keff = k > BANK_KEFF ? k : BANK_KEFF;
     if (rank == keff - 1) {
         float v = m;
-        if (v > -INFINITY) v = v - 1e-6f - 1e-6f * fabsf(v);
+        if (v > -INFINITY) v = v - 1e-6f - 1e-6f * fabsf(v) - margin;
         tau[q] = v;
     }
+}
+
+// max over rows of |hi plane| and |lo plane| (squared, as ordered uint bit patterns)
+__global__ __launch_bounds__(256) void bank_bounds_kernel(const uint16_t* __restrict__ bank, int64_t ld,
+                                                          int planes, int D, int64_t R,
+                                                          uint32_t* __restrict__ out_sq) {
+    const int lane = threadIdx.x & 63;
+    float mh = 0.f, ml = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (int64_t)gridDim.x * 4) {
+        const uint16_t* br = bank + r * ld;
+        float h2 = 0.f, l2 = 0.f;
+        for (int c = lane * 8; c < D; c += 512) {
+            const u32x4_t h = *(const u32x4_t*)(br + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __uint_as_float(h[e] << 16), b = __uint_as_float(h[e] & 0xffff0000u);
+                h2 = fmaf(a, a, fmaf(b, b, h2));
+            }
+            if (planes > 1) {
+                const u32x4_t l = *(const u32x4_t*)(br + D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = __uint_as_float(l[e] << 16), b = __uint_as_float(l[e] & 0xffff0000u);
+                    l2 = fmaf(a, a, fmaf(b, b, l2));
+                }
+            }
+        }
+        mh = fmaxf(mh, wave_sum(h2)); ml = fmaxf(ml, wave_sum(l2));
+    }
+    if (lane == 0) {
+        // NaN/inf rows: the uint order puts them on top, the margin becomes inf/NaN and the
+        // filter lists everything (-> overflow flag -> brute-force path); never a wrong result
+        atomicMax(out_sq, __float_as_uint(mh));
+        atomicMax(out_sq + 1, __float_as_uint(ml));
+    }
+}
+__global__ void bank_bounds_finish_kernel(float* b) {
+    b[0] = sqrtf(b[0]) * 1.0001f; b[1] = sqrtf(b[1]) * 1.0001f;
+}
+
+hipError_t launch_bank_bounds(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R, float* bounds,
+                              hipStream_t stream) {
+    hipError_t st = hipMemsetAsync(bounds, 0, 8, stream);
+    if (st != hipSuccess || R == 0) return st;
+    int64_t grid = (R + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bank_bounds_kernel, dim3((int)grid), dim3(256), 0, stream, bank, ld, planes, D, R,
+                       (uint32_t*)bounds);
+    hipLaunchKernelGGL(bank_bounds_finish_kernel, dim3(1), dim3(1), 0, stream, bounds);
+    return hipGetLastError();
 }
 
 struct BankEpilogue {
@@ -95,7 +174,7 @@ struct BankEpilogue {
     float count_thr;
 };
 
-template <bool FULL>
+template <bool FULL, bool FILTER>
 __device__ __forceinline__ void bank_tile_epilogue(const gemm_acc_t& acc, const BankEpilogue& e,
                                                    int64_t tile_row0, int chunk, int j0, int wm, int wn,
                                                    int lane, const float (&tau)[4], float (&sum)[4],
@@ -115,23 +194,26 @@ __device__ __forceinline__ void bank_tile_epilogue(const gemm_acc_t& acc, const 
                     if (row + r >= e.R) v[r] = -INFINITY;
             }
             const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (FULL) {
-                sum[n] += (v[0] + v[1]) + (v[2] + v[3]);
-                sq[n] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], sq[n]))));
-            } else {
+            if (!FILTER) {
+                if (FULL) {
+                    sum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    sq[n] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], sq[n]))));
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row + r < e.R) { sum[n] += v[r]; sq[n] = fmaf(v[r], v[r], sq[n]); }
-            }
-            mx[n] = fmaxf(mx[n], m4);
-            if (m4 >= e.count_thr) {
+                    for (int r = 0; r < 4; ++r)
+                        if (row + r < e.R) { sum[n] += v[r]; sq[n] = fmaf(v[r], v[r], sq[n]); }
+                }
+                mx[n] = fmaxf(mx[n], m4);
+                if (m4 >= e.count_thr) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cn[n] += (v[r] >= e.count_thr) ? 1.f : 0.f;
+                    for (int r = 0; r < 4; ++r) cn[n] += (v[r] >= e.count_thr) ? 1.f : 0.f;
+                }
             }
-            if (m4 > tau[n]) {
+            // NaN-safe: !(m4 <= tau) also lists rows when the bound is NaN (degenerate bank rows)
+            if (!(m4 <= tau[n])) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (v[r] > tau[n]) {
+                    if (!(v[r] <= tau[n]) && (FULL || row + r < e.R)) {
                         // rare path (a few survivors per lane per bank chunk): keep
                         // its address arithmetic inside the branch, not hoisted into
                         // registers that stay live across the main loop
@@ -151,6 +233,7 @@ __device__ __forceinline__ void bank_tile_epilogue(const gemm_acc_t& acc, const 
     }
 }
 
+template <bool FILTER>
 __global__ __launch_bounds__(GEMM_THREADS) void bank_search_kernel(GemmOperands g, BankEpilogue e,
                                                                    int nQt, int S, int tiles_per_chunk,
                                                                    int n_bank_tiles) {
@@ -185,11 +268,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void bank_search_kernel(GemmOperands 
         const int64_t tile_row0 = (int64_t)bt * GEMM_BM;
         gemm_mainloop(acc, g, (int)tile_row0, j0, smem);
         if (tile_row0 + GEMM_BM <= e.R)
-            bank_tile_epilogue<true>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
+            bank_tile_epilogue<true, FILTER>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
         else
-            bank_tile_epilogue<false>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
+            bank_tile_epilogue<false, FILTER>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
     }
 
+    if (FILTER) {
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int q = j0 + threadIdx.x;
+            if (q < e.M) {
+                int c = lds_cnt[threadIdx.x];
+                if (c > BANK_CAP) { c = BANK_CAP; atomicOr(e.overflow, 1); }
+                e.cand_cnt[(int64_t)chunk * e.M + q] = c;
+            }
+        }
+        return;
+    }
     // moments: the 4 lane groups of a wave and the 2 wm-waves share a query
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -229,8 +324,13 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
                                                           int k, int32_t* __restrict__ topk_idx,
                                                           float* __restrict__ topk_sim,
                                                           float* __restrict__ moments,
-                                                          int32_t* __restrict__ overflow) {
+                                                          int32_t* __restrict__ overflow,
+                                                          const uint16_t* __restrict__ rs_bank, int64_t rs_ld,
+                                                          int rs_planes, int D,
+                                                          const float* __restrict__ rs_rows,
+                                                          int64_t idx_offset) {
     __shared__ Cand pool[BANK_POOL];
+    __shared__ __attribute__((aligned(16))) float qs[BANK_MAX_RESCORE_D];
     __shared__ int scan[256];
     __shared__ float red_v[4];
     __shared__ int red_i[4];
@@ -262,7 +362,55 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
     }
     if (t == 0 && total_all > BANK_POOL) atomicOr(overflow, 2);
     const int total = total_all < BANK_POOL ? total_all : BANK_POOL;
+    if (rs_bank) {
+        for (int c = t; c < D; c += 256) qs[c] = rs_rows[(int64_t)q * D + c];
+    }
     __syncthreads();
+
+    if (rs_bank) {
+        // exact fp32 re-scoring of the listed rows: one wave per row, four rows in flight
+        for (int i0 = wave; i0 < total; i0 += 16) {
+            float part[4];
+            const uint16_t* br[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int i = i0 + u * 4;
+                i = i < total ? i : total - 1;
+                br[u] = rs_bank + ((int64_t)pool[i].idx - idx_offset) * rs_ld;
+                part[u] = 0.f;
+            }
+            for (int c = lane * 8; c < D; c += 512) {
+                u32x4_t h[4], l[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    h[u] = *(const u32x4_t*)(br[u] + c);
+                    if (rs_planes > 1) l[u] = *(const u32x4_t*)(br[u] + D + c);
+                }
+                const f32x4_t q0 = *(const f32x4_t*)(qs + c), q1 = *(const f32x4_t*)(qs + c + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        float a = __uint_as_float(h[u][e2] << 16), b = __uint_as_float(h[u][e2] & 0xffff0000u);
+                        if (rs_planes > 1) {
+                            a += __uint_as_float(l[u][e2] << 16);
+                            b += __uint_as_float(l[u][e2] & 0xffff0000u);
+                        }
+                        const float qa = e2 < 2 ? q0[e2 * 2] : q1[e2 * 2 - 4];
+                        const float qb = e2 < 2 ? q0[e2 * 2 + 1] : q1[e2 * 2 - 3];
+                        part[u] = fmaf(a, qa, fmaf(b, qb, part[u]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = wave_sum(part[u]);
+                const int i = i0 + u * 4;
+                if (lane == 0 && i < total) pool[i].v = v;
+            }
+        }
+        __syncthreads();
+    }
 
     for (int r = 0; r < k; ++r) {
         float bv = -INFINITY;
@@ -406,8 +554,11 @@ hipError_t launch_bank_search_dense(const BankSearchLaunch& L, float* sims_ws, i
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)bank_search_kernel,
+        hipError_t st = hipFuncSetAttribute((const void*)bank_search_kernel<false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
+        if (st != hipSuccess) return st;
+        st = hipFuncSetAttribute((const void*)bank_search_kernel<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
         if (st != hipSuccess) return st;
         attr_done = true;
     }
@@ -418,6 +569,8 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     const int planes = (L.bank_planes == 2) ? 3 : 2;
     const int a_off[4] = {0, 0, D, 0};          // bank plane offsets
     const int b_off[4] = {0, D, 0, 0};          // query plane offsets
+    // fast form: one-product filter + exact re-scoring (needs no per-row moments)
+    const bool filter = (L.moments == nullptr) && L.bank_bounds && L.rows && D <= BANK_MAX_RESCORE_D && L.allow_filter;
 
     // ---- pass 0: sample GEMM + tau ----------------------------------------
     GemmLaunch G;
@@ -427,7 +580,8 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     G.out = L.s0; G.ldo = L.n_sample; G.epilogue = TVC_EPI_F32;
     hipError_t st = launch_gemm_bf16(G, stream);
     if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(kth_bound_kernel, dim3(L.M), dim3(256), 0, stream, L.s0, L.n_sample, L.k, L.tau);
+    hipLaunchKernelGGL(kth_bound_kernel, dim3(L.M), dim3(256), 0, stream, L.s0, L.n_sample, L.k, L.tau,
+                       filter ? L.qplanes : nullptr, D, L.bank_bounds);
     st = hipGetLastError();
     if (st != hipSuccess) return st;
     st = hipMemsetAsync(L.overflow, 0, sizeof(int32_t), stream);
@@ -437,7 +591,7 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     GemmOperands g;
     g.A = L.bank; g.lda = L.ldb; g.I = (int)L.R;
     g.B = L.qplanes; g.ldb = 2 * (int64_t)D; g.J = L.M;
-    g.ksteps_per_plane = D / GEMM_BK; g.planes = planes;
+    g.ksteps_per_plane = D / GEMM_BK; g.planes = filter ? 1 : planes;
     for (int p = 0; p < 4; ++p) { g.a_plane_off[p] = a_off[p]; g.b_plane_off[p] = b_off[p]; }
     BankEpilogue e;
     e.tau = L.tau; e.cand = (Cand*)L.cand; e.cand_cnt = L.cand_cnt; e.mom_part = L.mom_part;
@@ -445,14 +599,19 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     const int nQt = (L.M + GEMM_BN - 1) / GEMM_BN;
     const int nbt = (int)((L.R + GEMM_BM - 1) / GEMM_BM);
     const int tpc = (nbt + L.S - 1) / L.S;
-    hipLaunchKernelGGL(bank_search_kernel, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
-                       g, e, nQt, L.S, tpc, nbt);
+    if (filter)
+        hipLaunchKernelGGL(bank_search_kernel<true>, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
+                           g, e, nQt, L.S, tpc, nbt);
+    else
+        hipLaunchKernelGGL(bank_search_kernel<false>, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
+                           g, e, nQt, L.S, tpc, nbt);
     st = hipGetLastError();
     if (st != hipSuccess) return st;
 
     // ---- pass 2: select -----------------------------------------------------
     hipLaunchKernelGGL(bank_select_kernel, dim3(L.M), dim3(256), 0, stream, (const Cand*)L.cand,
-                       L.cand_cnt, L.mom_part, L.S, L.M, L.k, L.topk_idx, L.topk_sim, L.moments, L.overflow);
+                       L.cand_cnt, L.mom_part, L.S, L.M, L.k, L.topk_idx, L.topk_sim, L.moments, L.overflow,
+                       filter ? L.bank : nullptr, L.ldb, L.bank_planes, D, L.rows, L.idx_offset);
     return hipGetLastError();
 }
 

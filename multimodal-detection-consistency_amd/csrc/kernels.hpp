@@ -58,6 +58,9 @@ struct BankSearchLaunch {
     int D = 0;
     int bank_planes = 1;              // 1 = bf16 bank, 2 = (hi | lo) split of an fp32 bank
     const uint16_t* qplanes = nullptr;// [M, 2*D] bf16 (hi | lo) query planes
+    const float* rows = nullptr;      // [M, D] the fp32 query rows (exact re-scoring of the fast form)
+    const float* bank_bounds = nullptr;// [2] device: max |hi plane row|, max |lo plane row|
+    bool allow_filter = true;         // one-product filter + re-scoring when no moments are requested
     int M = 0;
     int k = 0;
     float count_thr = 0.f;
@@ -77,6 +80,8 @@ struct BankSearchLaunch {
 };
 void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap);
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream);
+hipError_t launch_bank_bounds(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R, float* bounds,
+                              hipStream_t stream);
 // brute force: sims_ws fp32 [block_rows, R]
 hipError_t launch_bank_search_dense(const BankSearchLaunch& L, float* sims_ws, int block_rows, hipStream_t stream);
 hipError_t launch_topk_merge(const int32_t* idx_parts, const float* sim_parts, const float* feat_parts,

@@ -51,6 +51,8 @@ struct tvc_handle {
     int64_t R = 0;
     int D = 0;
     int bank_planes = 1;
+    float* bank_bounds = nullptr;     // device [2]: max row norms of the bank planes
+    bool bank_filter = true;          // TVC_OPT_BANK_FILTER
     Buf ws[WS_COUNT];
     std::string err;
     int max_chunk_images = 512;
@@ -241,6 +243,7 @@ void tvc_destroy(tvc_handle* h) {
     if (!h) return;
     for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
     if (h->bank_owned) (void)hipFree(h->bank_owned);
+    if (h->bank_bounds) (void)hipFree(h->bank_bounds);
     delete h;
 }
 
@@ -361,6 +364,9 @@ int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D, int3
     } else {
         return fail(h, TVC_E_INVALID, "tvc_bank_set: dtype must be TVC_DTYPE_BF16 or TVC_DTYPE_F32");
     }
+    if (!h->bank_bounds) HIP_TRY(hipMalloc((void**)&h->bank_bounds, 8));
+    HIP_TRY(launch_bank_bounds(h->bank, (int64_t)h->bank_planes * D, h->bank_planes, D, R, h->bank_bounds,
+                               (hipStream_t)stream));
     h->R = R;
     return TVC_OK;
 }
@@ -397,12 +403,14 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     L.bank = h->bank; L.ldb = (int64_t)h->bank_planes * D; L.R = h->R; L.D = D; L.bank_planes = h->bank_planes;
     L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
+    L.rows = rows_dev; L.bank_bounds = h->bank_bounds; L.allow_filter = h->bank_filter;
     L.s0 = (float*)h->ws[WS_S0].p; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
     L.cand_cnt = (int32_t*)h->ws[WS_CAND_CNT].p; L.mom_part = (float*)h->ws[WS_MOM_PART].p;
     L.overflow = (int32_t*)h->ws[WS_OVERFLOW].p;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
     {
-        const int planes = h->bank_planes == 2 ? 3 : 2;
+        const bool filter = !moments_dev && h->bank_filter && D <= 2048;
+        const int planes = filter ? 1 : (h->bank_planes == 2 ? 3 : 2);
         ProfScope ps(h, st, TVC_PROF_BANK, 2.0 * (double)h->R * M * D * planes);
         HIP_TRY(launch_bank_search(L, st));
     }
@@ -538,6 +546,7 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
     if (!h) return TVC_E_INVALID;
     switch (option) {
         case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
+        case TVC_OPT_BANK_FILTER: h->bank_filter = value != 0; return TVC_OK;
         case TVC_OPT_MAX_CHUNK_IMAGES:
             if (value < 1) return fail(h, TVC_E_INVALID, "tvc_set_option: chunk must be >= 1");
             h->max_chunk_images = (int)value; return TVC_OK;

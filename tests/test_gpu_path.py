@@ -62,6 +62,42 @@ def test_bank_search(gpu_engine, R, M, D, k, dtype):
     assert (np.abs(mom[:, 3] - cnt) <= near.sum(1)).all()
 
 
+@pytest.mark.parametrize("R,M,D,k,dtype,scale", [
+    (20, 3, 512, 10, torch.float32, 1.0),
+    (1000, 48, 512, 5, torch.bfloat16, 1.0),
+    (70001, 70, 768, 20, torch.bfloat16, 1.0),
+    (3, 5, 128, 5, torch.bfloat16, 1.0),
+    (4097, 257, 256, 32, torch.float32, 1.0),
+    (30000, 300, 512, 5, torch.float32, 3.7),    # un-normalised bank rows: the margin scales with the row norms
+    (200000, 64, 768, 5, torch.bfloat16, 1.0),
+])
+def test_bank_search_filter_form(gpu_engine, pkg, R, M, D, k, dtype, scale):
+    """No moments requested -> one-product filter + fp32 re-scoring (tvc.h TVC_OPT_BANK_FILTER):
+    same top-k as the exact fp64 product, and the same index sets as the all-products pass."""
+    bank = (_unit((R, D), 100 + R) * scale).to(dtype)
+    q = _unit((M, D), 200 + M)
+    gpu_engine.set_bank(bank.cuda())
+    idx, sim, mom = gpu_engine.bank_search(q.cuda(), k, want_moments=False)
+    gpu_engine.bank_status()
+    assert mom is None
+    S = (q.double() @ bank.double().t()).numpy()
+    _check_topk(idx.cpu().numpy(), sim.cpu().numpy().astype(np.float64), S, k, 1e-5 * scale)
+    try:
+        gpu_engine.set_option(pkg._lib.TVC_OPT_BANK_FILTER, 0)
+        idx2, sim2, _ = gpu_engine.bank_search(q.cuda(), k, want_moments=False)
+        gpu_engine.bank_status()
+    finally:
+        gpu_engine.set_option(pkg._lib.TVC_OPT_BANK_FILTER, 1)
+    valid = idx >= 0
+    assert (valid == (idx2 >= 0)).all()
+    assert (sim[valid] - sim2[valid]).abs().max().item() < 2e-6 * scale
+    same = (idx == idx2).all(dim=1)
+    # rows may differ only where neighbouring similarities tie within the fp32 rounding of the two sums
+    for m in (~same).nonzero().flatten().tolist():
+        assert sorted(idx[m].tolist()) == sorted(idx2[m].tolist()) or \
+            np.abs(np.diff(np.sort(S[m])[::-1][:k + 1])).min() < 2e-6 * scale
+
+
 def test_bank_search_ties_and_duplicates(gpu_engine):
     """Duplicate rows: equal similarities must come back ordered by index."""
     D = 128
@@ -227,17 +263,23 @@ def test_two_shard_search_equals_full_search(gpu_engine):
     bank = _unit((R, D), 31).to(torch.bfloat16).cuda()
     q = _unit((M, D), 32).cuda()
     gpu_engine.set_bank(bank)
-    fi, fs, _ = gpu_engine.bank_search(q, k, want_moments=False)
-    ff = gpu_engine.bank_gather(fi[:, :kf].contiguous())
-    gpu_engine.bank_status()
-    parts_i, parts_s, parts_f, parts_m = [], [], [], []
-    for lo, hi in ((0, 3000), (3000, R)):
-        gpu_engine.set_bank(bank[lo:hi].contiguous())
-        i, s, m = gpu_engine.bank_search(q, k, 0.05, idx_offset=lo)
-        f = gpu_engine.bank_gather(i[:, :kf].contiguous(), idx_offset=lo)
-        gpu_engine.bank_status()
-        parts_i.append(i); parts_s.append(s); parts_f.append(f); parts_m.append(m)
-    mi, ms, mf, mm = gpu_engine.topk_merge(torch.stack(parts_i), torch.stack(parts_s), torch.stack(parts_f), torch.stack(parts_m))
-    assert torch.equal(mi, fi) and torch.equal(ms, fs) and torch.equal(mf, ff)
     S = q.double() @ bank.double().t()
-    assert (mm[:, 3].cpu() - (S >= 0.05).sum(1).cpu()).abs().max() <= 1
+    for want_moments in (True, False):       # all-products pass with moments / filter + re-score form
+        gpu_engine.set_bank(bank)
+        fi, fs, _ = gpu_engine.bank_search(q, k, 0.05, want_moments=want_moments)
+        ff = gpu_engine.bank_gather(fi[:, :kf].contiguous())
+        gpu_engine.bank_status()
+        parts_i, parts_s, parts_f, parts_m = [], [], [], []
+        for lo, hi in ((0, 3000), (3000, R)):
+            gpu_engine.set_bank(bank[lo:hi].contiguous())
+            i, s, m = gpu_engine.bank_search(q, k, 0.05, idx_offset=lo, want_moments=want_moments)
+            f = gpu_engine.bank_gather(i[:, :kf].contiguous(), idx_offset=lo)
+            gpu_engine.bank_status()
+            parts_i.append(i); parts_s.append(s); parts_f.append(f)
+            if want_moments:
+                parts_m.append(m)
+        mi, ms, mf, mm = gpu_engine.topk_merge(torch.stack(parts_i), torch.stack(parts_s), torch.stack(parts_f),
+                                               torch.stack(parts_m) if want_moments else None)
+        assert torch.equal(mi, fi) and torch.equal(ms, fs) and torch.equal(mf, ff)
+        if want_moments:
+            assert (mm[:, 3].cpu() - (S >= 0.05).sum(1).cpu()).abs().max() <= 1

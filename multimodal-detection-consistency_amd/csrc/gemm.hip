@@ -3,6 +3,15 @@
 #include "gemm_ring.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
+
+// s_setprio levels of the MFMA phases of the two wave groups of the ring kernel (see gemm_ring_kernel)
+#ifndef TVC_PRIO_G0
+#define TVC_PRIO_G0 1
+#endif
+#ifndef TVC_PRIO_G1
+#define TVC_PRIO_G1 2
+#endif
 
 struct GemmEpilogue {
     const float* bias;     // [I] or nullptr
@@ -97,6 +106,28 @@ __device__ __forceinline__ void gemm_tile_epilogue(const gemm_acc_t& acc, const 
                 float* p = (float*)e.out + (int64_t)j * e.ldo + i0 + il;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) *(f32x4_t*)(p + m * 16) = acc[m][n] + bias_of(m);
+            } else if ((e.ldo & 7) == 0) {
+                // bf16 outputs: a lane's 4 features are 8 B and the 4 lanes of a token cover 32 B per
+                // sub-tile.  Swapping 16-lane rows between the sub-tiles m and m+1
+                // (v_permlane16_swap: odd rows of X <-> even rows of Y) leaves every lane with 8
+                // consecutive features, so it stores 16 B and a token gets 64 contiguous bytes per
+                // store instruction: half the store instructions, twice the segment size.
+                const int gq = lane >> 4;
+                uint16_t* p = (uint16_t*)e.out + (int64_t)j * e.ldo + i0 + wm * 128 + (gq & 1) * 16 + (gq >> 1) * 8;
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp) {
+                    f32x4_t v0 = acc[2 * mp][n] + bias_of(2 * mp);
+                    f32x4_t v1 = acc[2 * mp + 1][n] + bias_of(2 * mp + 1);
+                    if (EPI == TVC_EPI_GELU_BF16) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { v0[t] = quick_gelu(v0[t]); v1[t] = quick_gelu(v1[t]); }
+                    }
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+                    u32x4_t o;
+                    o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
+                    *(u32x4_t*)(p + mp * 32) = o;
+                }
             } else {
                 uint16_t* p = (uint16_t*)e.out + (int64_t)j * e.ldo + i0 + il;
 #pragma unroll
@@ -153,6 +184,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmOperands g,
 // ---------------------------------------------------------------------------
 // Persistent ring-pipelined variant (gemm_ring.hpp): used for the big tower GEMMs.
 // ---------------------------------------------------------------------------
+#ifdef TVC_RING_STAMPS
+// diagnostic build only (scripts/ring_stamps.py): per-wave shader-clock totals of the loop phases
+__device__ unsigned long long ring_stamps[256 * 8 * 8];
+extern "C" int tvc_debug_ring_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_stamps), sizeof(ring_stamps));
+}
+__device__ unsigned long long ring_trace[4 * 512];
+extern "C" int tvc_debug_ring_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_trace), sizeof(ring_trace));
+}
+#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; \
+                   if ((i) == 5 && S < 512 && lane == 0 && (blockIdx.x == 8 || blockIdx.x == 100) && (wave & 3) == 0) \
+                       ring_trace[((blockIdx.x == 100) * 2 + (wave >> 2)) * 512 + S] = t_; }
+#else
+#define STAMP(i)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -168,6 +215,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     const int total = my_tiles * nk;                               // stages in this workgroup's stream
     if (total == 0) return;
 
+#ifdef TVC_RING_STAGGER
+    // XCD x starts x/8 of a tile period late: the tile epilogues (a 4 MiB dirty burst per XCD) of
+    // different XCDs no longer hit HBM at the same time
+    for (int i = (blockIdx.x & 7) * nk * TVC_RING_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+#endif
     const uint32_t smem_lds = lds_addr(smem);
     // ---- issue side: scalar tile bases + per-lane 32-bit offsets (recomputed per tile only)
     int is_tile = 0, is_p = 0, is_kk = 0, is_n = 0;
@@ -234,7 +286,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     gemm_acc_t acc;
     gemm_zero_acc(acc);
     bf16x8_t a[8], b[4];
-    int credit = 0;              // upcoming waits that still see a fast epilogue's 32 stores in the queue
+    int credit = 0;              // upcoming waits that still see a fast epilogue's stores in the queue
+    const bool st16 = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) && (e.ldo & 7) == 0;
     int ct = 0, cks = 0;         // tile / k-stage of the stage the MFMAs of this wave work on
 
     auto tile_origin = [&](int t, int& i0, int& j0) {
@@ -249,8 +302,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
 #pragma unroll
         for (int n = 0; n < 4; ++n) b[n] = *(const bf16x8_t*)(slot + b_off + n * 1024);
     };
-    auto mfma_stage = [&]() {
-        __builtin_amdgcn_s_setprio(1);
+    auto mfma_stage = [&](auto prio) {
+        __builtin_amdgcn_s_setprio(decltype(prio)::value);
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -272,7 +325,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     };
     auto retire_and_barrier = [&](int S) {
         const int n_out = (S + 3 < total ? S + 3 : total - 1) - S;           // stages in flight beyond S
-        if (n_out >= 3 && credit > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+        // a fast epilogue left 32 (16 for the 16-byte bf16 form) stores in the queue behind the loads
+        if (n_out >= 3 && credit > 0 && st16) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+        else if (n_out >= 3 && credit > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
         else if (n_out >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (n_out == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -281,9 +336,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
         asm volatile("" ::: "memory");
     };
 
+#ifdef TVC_RING_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     if (gid == 0) {
         int it = 0, iks = 0;     // tile / k-stage of the stage being loaded (== multiplied) this interval
         for (int S = 0; S < total; ++S) {
+            STAMP(0)
             if (S + 3 < total) issue();
             if (iks == 0 && wave == 0 && e.bias) {
                 // the tile's 256 bias values -> one of TWO alternating LDS slots (group 1 may still be
@@ -294,22 +354,36 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
                 if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (it & 1) * 1024);
             }
             if (++iks == nk) { iks = 0; ++it; }
+            STAMP(1)
             load_frags(S);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mfma_stage();
+            STAMP(2)
+            mfma_stage(std::integral_constant<int, TVC_PRIO_G0>{});
+            STAMP(3)
             finish_stage(3);
+            STAMP(4)
             retire_and_barrier(S);
+            STAMP(5)
         }
     } else {
         for (int S = 0; S < total; ++S) {
-            if (S > 0) { mfma_stage(); finish_stage(2); }
+            STAMP(0)
+            if (S > 0) { mfma_stage(std::integral_constant<int, TVC_PRIO_G1>{}); STAMP(3) finish_stage(2); STAMP(4) }
             if (S + 3 < total) issue();
+            STAMP(1)
             load_frags(S);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(2)
             retire_and_barrier(S);
+            STAMP(5)
         }
-        mfma_stage();
+        mfma_stage(std::integral_constant<int, TVC_PRIO_G1>{});
         finish_stage(0);
     }
+#ifdef TVC_RING_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) ring_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
+#endif
 }
 
 static hipError_t set_lds_attr_once() {

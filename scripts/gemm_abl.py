@@ -15,4 +15,5 @@ def bench(I, J, K, epi, iters=6):
     for _ in range(iters): eng.gemm(a, b, bias, epi, out=out)
     t1.record(); torch.cuda.synchronize()
     return t0.elapsed_time(t1) / iters
-print(os.environ.get("TVC_LIB_PATH", "full"), " fc2 %.3f ms  fc1 %.3f ms  qkv %.3f ms" % (bench(1024, 131072, 4096, 3), bench(4096, 131072, 1024, 2), bench(3072, 131072, 1024, 1)))
+print(os.environ.get("TVC_LIB_PATH", "full"), " fc2 %.3f ms  fc1 %.3f ms  qkv %.3f ms  proj %.3f ms" % (
+    bench(1024, 131072, 4096, 1), bench(4096, 131072, 1024, 2), bench(3072, 131072, 1024, 1), bench(1024, 131072, 1024, 1)))

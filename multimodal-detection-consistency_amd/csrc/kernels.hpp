@@ -18,6 +18,7 @@ struct GemmLaunch {
     void* out = nullptr;           // [J, ldo]
     int64_t ldo = 0;
     int epilogue = TVC_EPI_F32;
+    bool no_solo = false;          // internal: remainder launch of a split GEMM
 };
 hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 

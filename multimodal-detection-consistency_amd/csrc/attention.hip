@@ -22,7 +22,11 @@
 #define ATT_KROW 128     // K image: 64 bf16 per row
 #define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
 
-template <int MAXT, bool CAUSAL, int WPS>
+// EXACT: every sequence has exactly MAXT key tiles (fixed-length, non-causal: the vision tower).
+// The per-tile guards become compile-time true, so the 16-key tiles of a query block are
+// straight-line code and their LDS reads / MFMAs / exps interleave instead of running as MAXT
+// dependent chains separated by scalar branches.
+template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv,
                                                         uint16_t* __restrict__ out,
                                                         const int32_t* __restrict__ starts, int T_fixed,
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         row0 = s0; T = s1 - s0;
     } else { row0 = (int64_t)seq * T_fixed; T = T_fixed; }
     if (T > MAXT * 16) T = MAXT * 16;      // host guarantees this; never index past the region
-    const int NT = (T + 15) >> 4;          // key tiles of 16
+    const int NT = EXACT ? MAXT : (T + 15) >> 4;          // key tiles of 16
     const int NP = (NT + 1) >> 1;          // key pairs of 32
     const int KT = NT * 16, VT = NP * 32;
     char* ldsK = smem + item_local * region_bytes;
@@ -125,10 +129,32 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         const int qr = qb * 16 + r16;
         const bf16x8_t bq0 = nq0, bq1 = nq1;
         if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
-        const int nt_q = CAUSAL ? ((qb + 1 < NT) ? qb + 1 : NT) : NT;
+        const int nt_q = EXACT ? MAXT : (CAUSAL ? ((qb + 1 < NT) ? qb + 1 : NT) : NT);
 
         f32x4_t s[MAXT];
         float mx = -INFINITY;          // max of the RAW scores (scaling by a positive constant is monotonic)
+        if (EXACT) {
+            // two passes over the key tiles (dh 0-31, then dh 32-63): MAXT independent MFMAs per
+            // pass instead of MAXT dependent pairs
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const f32x4_t c0 = (t == MAXT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const bf16x8_t a0 = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, c0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const bf16x8_t a1 = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw1);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
+            }
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                m0 = fmaxf(m0, fmaxf(s[t][0], s[t][1]));
+                m1 = fmaxf(m1, fmaxf(s[t][2], s[t][3]));
+            }
+            mx = fmaxf(m0, m1);
+        } else {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -146,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, c0, 0, 0, 0);
                 mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             }
+        }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -211,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     }
 }
 
-template <int MAXT, bool CAUSAL, int WPS>
+template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
                              int max_T, int heads, hipStream_t stream) {
     const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
@@ -221,13 +248,13 @@ static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* 
     const size_t lds = (size_t)region * IPW;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS>,
+        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS, EXACT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (st != hipSuccess) return st;
         attr_done = true;
     }
     const int n_items = n_seq * heads;
-    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS>), dim3((n_items + IPW - 1) / IPW), dim3(256), lds, stream,
+    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT>), dim3((n_items + IPW - 1) / IPW), dim3(256), lds, stream,
                        qkv, out, starts, T, heads, n_items, k_bytes, region);
     return hipGetLastError();
 }
@@ -244,6 +271,8 @@ hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* s
         if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
         return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
     }
+    if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);   // ViT-L/14: 257 tokens
+    if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);     // ViT-B/32: 50 tokens
     if (NT <= 2) return launch_one<2, false, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
     if (NT <= 4) return launch_one<4, false, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
     if (NT <= 6) return launch_one<6, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);

@@ -192,6 +192,25 @@ def main():
                 "traffic": None, "launches_per_step": g["launches"],
                 "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
 
+    if roof is not None and rank == 0:
+        # HBM bytes per launch of the dominant kernel family from the committed PMC summary of this
+        # command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bench.py cannot collect counters)
+        try:
+            import glob
+            import json as _json
+            here = os.path.dirname(os.path.abspath(__file__))
+            files = sorted(glob.glob(os.path.join(here, "profiles", "*hbm_traffic_pmc.json")))
+            if files and a.model == "ViT-L/14" and B == 512 and N == 8 and R == 1_000_000:
+                pm = _json.load(open(files[-1]))
+                ring = [(v["launches"], v["hbm_MB_per_launch_corrected"]) for k, v in pm.items()
+                        if k.startswith("gemm_ring_kernel")]
+                if ring:
+                    roof["traffic"] = round(sum(n * mb for n, mb in ring) / sum(n for n, _ in ring) / 1e3, 3)
+                    roof["traffic_unit"] = "GB per launch (PMC, launch-weighted mean over the ring GEMMs)"
+                    roof["traffic_source"] = "profiles/" + os.path.basename(files[-1])
+        except Exception:       # a missing / unreadable summary leaves traffic null
+            pass
+
     if rank == 0:
         qps = world * B * a.steps / dt
         flops_q = arch.flops_image() + (N + 1) * arch.flops_text() + 2.0 * (N + 2) * R * D

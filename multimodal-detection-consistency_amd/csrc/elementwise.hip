@@ -225,16 +225,31 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
     const int t = threadIdx.x;
     if (t == 0) { carry_s = 0; maxlen_s = 0; }
     __syncthreads();
+    // phase A: one wave per text, coalesced token reads; len = position of the first maximum id + 1
+    // (parked in starts[n], which phase B overwrites in place)
+    {
+        const int lane = t & 63, wave = t >> 6;
+        for (int n = wave; n < n_text; n += 16) {
+            int best = -1, best_t = 0;
+            for (int tt = lane; tt < ctx; tt += 64) {
+                const int v = tok[(int64_t)n * ctx + tt];
+                if (v > best) { best = v; best_t = tt; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ov = __shfl_xor(best, o, 64);
+                const int ot = __shfl_xor(best_t, o, 64);
+                if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
+            }
+            if (lane == 0) starts[n] = best_t + 1;
+        }
+    }
+    __syncthreads();
     for (int base = 0; base < n_text; base += 1024) {
         const int n = base + t;
         int len = 0;
         if (n < n_text) {
-            int best = -1, best_t = 0;
-            for (int tt = 0; tt < ctx; ++tt) {
-                const int v = tok[(int64_t)n * ctx + tt];
-                if (v > best) { best = v; best_t = tt; }
-            }
-            len = best_t + 1;
+            len = starts[n];
             atomicMax(&maxlen_s, len);
         }
         part[t] = len;

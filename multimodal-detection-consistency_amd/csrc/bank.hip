@@ -240,10 +240,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void bank_search_kernel(GemmOperands 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds_cnt = (int*)(smem + GEMM_LDS_BYTES);
     float* lds_mom = (float*)(smem + GEMM_LDS_BYTES + 256 * 4);
-    // query tile slowest: an XCD owns ~2-3 query tiles (their planes stay in its
-    // L2) and streams the whole bank
+    // Order of the (query tile, bank chunk) items inside an XCD (consecutive `lin` = concurrently
+    // resident workgroups): blocks of 4 query tiles x 8 chunks, so the 32 workgroups of a block keep
+    // 4 query tiles (1.6 MB of planes) in the XCD's L2 AND read every bank tile four times from L2 for
+    // one HBM read (query-tile-slowest order streamed the whole bank once per query tile: 30 GB per
+    // launch at cfg 2).  Ragged counts fall back to query tile slowest.
     const int lin = xcd_contiguous(blockIdx.x, nQt * S);
-    const int qt = lin / S, chunk = lin - qt * S;
+    int qt, chunk;
+    if ((nQt & 3) == 0 && (S & 7) == 0) {
+        const int blk = lin >> 5, r = lin & 31;
+        const int ncg = S >> 3;
+        const int qg = blk / ncg, cg = blk - qg * ncg;
+        qt = qg * 4 + (r & 3);
+        chunk = cg * 8 + (r >> 2);
+    } else {
+        qt = lin / S; chunk = lin - qt * S;
+    }
     const int j0 = qt * GEMM_BN;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

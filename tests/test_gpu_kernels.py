@@ -128,3 +128,31 @@ def test_cosine_matrix(gpu_engine, pkg, N, M, D):
     assert rc == 0
     # split-bf16 (3 products) + fp32 accumulate: 1e-5 absolute on cosines (bar: 1e-4)
     assert (out.double().cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_gemm_four_wave_variant_in_subprocess():
+    """TVC_GEMM_VARIANT=2 (read once per process) selects gemm_solo_kernel for the ring-eligible bf16
+    GEMMs: same outputs as the PyTorch restatement, including a ragged token remainder."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch, tvc_amd as pkg
+eng = pkg.TVCEngine()
+g = torch.Generator(device="cuda:0").manual_seed(11)
+for I, J, K, epi in ((1024, 2048, 1024, 1), (768, 3000, 640, 2), (3072, 12800, 768, 2), (256, 2304, 4096, 1)):
+    a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    bias = torch.randn(I, device="cuda:0", generator=g) * 3.0
+    out = eng.gemm(a, b, bias, epi).float()
+    ref = b.float() @ a.float().t() + bias
+    if epi == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    err = (out - ref).abs().max().item()
+    assert err < 1e-2 * (1 + ref.abs().max().item()), (I, J, K, epi, err)
+print("SOLO_OK")
+'''
+    env = dict(os.environ, TVC_GEMM_VARIANT="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SOLO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

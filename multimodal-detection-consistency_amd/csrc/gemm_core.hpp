@@ -60,12 +60,14 @@ __device__ __forceinline__ void gemm_stage_tile(const uint16_t* __restrict__ bas
 }
 
 // acc must be zero-initialised by the caller (or carry a running sum).
+// [step_begin, step_end): range of 64-deep K steps (over all planes) to multiply; the default is
+// the whole K (split-K partial tiles pass a sub-range).
 __device__ __forceinline__ void gemm_mainloop(gemm_acc_t& acc, const GemmOperands& g,
-                                              int i0, int j0, char* smem) {
+                                              int i0, int j0, char* smem, int step_begin = 0, int step_end = -1) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int nk = g.planes * g.ksteps_per_plane;
+    const int nk = (step_end < 0 ? g.planes * g.ksteps_per_plane : step_end) - step_begin;
 
     // lane-constant swizzled chunk offsets for k-sub-steps 0 and 1
     const int sw0 = ((0 + (lane >> 4)) ^ ((lane >> 1) & 7)) * 16;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void gemm_mainloop(gemm_acc_t& acc, const GemmOperand
     const int a_row_off = (wm * 128 + (lane & 15)) * 128;
     const int b_row_off = (wn * 64 + (lane & 15)) * 128;
 
-    int p = 0, kk = 0;   // plane / k-step-in-plane of the NEXT tile to stage
+    int p = step_begin / g.ksteps_per_plane, kk = step_begin - p * g.ksteps_per_plane;   // plane / k-step-in-plane of the NEXT tile to stage
     auto stage_next = [&](int buf) {
         const int aoff = g.a_plane_off[p] + kk * GEMM_BK;
         const int boff = g.b_plane_off[p] + kk * GEMM_BK;

@@ -19,6 +19,9 @@ struct GemmLaunch {
     int64_t ldo = 0;
     int epilogue = TVC_EPI_F32;
     bool no_solo = false;          // internal: remainder launch of a split GEMM
+    // optional scratch for the split-K tail (see launch_gemm_bf16); nullptr disables it
+    float* splitk_ws = nullptr;
+    size_t splitk_ws_bytes = 0;
 };
 hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 

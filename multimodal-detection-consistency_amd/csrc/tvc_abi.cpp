@@ -18,8 +18,8 @@ thread_local std::string g_create_error;
 enum Slot {
     // tower workspaces exist twice (vision, text: + WS_TOWER_N) so that the two towers can run
     // concurrently on two streams
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_TOWER_N,
-    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA,
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_SPLITK, WS_TOWER_N,
+    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TSPLITK,
     WS_PATCH, WS_EOT, WS_STARTS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
@@ -114,8 +114,14 @@ struct ProfScope {
 
 double gemm_flops(const GemmLaunch& g) { return 2.0 * g.I * (double)g.J * g.K * g.planes; }
 
-hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st) {
+hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st, int splitk_slot = -1) {
     ProfScope ps(h, st, TVC_PROF_GEMM, gemm_flops(g));
+    if (splitk_slot >= 0 && h->ws[splitk_slot].p) {
+        GemmLaunch g2 = g;
+        g2.splitk_ws = (float*)h->ws[splitk_slot].p;
+        g2.splitk_ws_bytes = h->ws[splitk_slot].n;
+        return launch_gemm_bf16(g2, st);
+    }
     return launch_gemm_bf16(g, st);
 }
 
@@ -151,7 +157,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
             const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
             const double fl = 4.0 * n_seq * a.heads * avg_len * avg_len * 64 * (causal ? 0.5 : 1.0);
@@ -161,7 +167,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bo; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 12.0);
             HIP_TRY(launch_layernorm(X, d, nullptr, D, 1, w.ln2_g, w.ln2_b, H, rows, d, st));
@@ -169,11 +175,11 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
         g.bias = w.b2; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         delta = D;
     }
     return TVC_OK;
@@ -187,6 +193,9 @@ int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_
     if ((rc = ensure(h, (Slot)(WS_MLP + wso), (size_t)rows * a.mlp * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_CLS + wso), (size_t)n_seq * a.width * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_DELTA + wso), (size_t)rows * a.width * 2))) return rc;
+    // fp32 partial tiles of the split-K tail (<= 256 partial tiles of 256 KiB), only worth having
+    // when the GEMMs are big enough for the persistent kernel
+    if (rows >= 256 * 128 && (rc = ensure(h, (Slot)(WS_SPLITK + wso), (size_t)256 * 256 * 256 * 4))) return rc;
     return TVC_OK;
 }
 
@@ -591,6 +600,11 @@ int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev, c
     GemmLaunch g;
     g.A = a_dev; g.lda = K; g.I = I; g.B = b_dev; g.ldb = K; g.J = J; g.K = K;
     g.bias = bias_dev; g.out = out_dev; g.ldo = ld_out; g.epilogue = epilogue;
+    if ((int64_t)((I + 255) / 256) * ((J + 255) / 256) >= 512) {       // persistent-kernel sizes: split-K tail scratch
+        int rc = ensure(h, WS_SPLITK, (size_t)256 * 256 * 256 * 4);
+        if (rc) return rc;
+        g.splitk_ws = (float*)h->ws[WS_SPLITK].p; g.splitk_ws_bytes = h->ws[WS_SPLITK].n;
+    }
     HIP_TRY(launch_gemm_bf16(g, (hipStream_t)stream));
     return TVC_OK;
 }

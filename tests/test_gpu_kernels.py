@@ -57,6 +57,26 @@ def test_gemm_persistent_many_tiles(gpu_engine, I, J, K, epi):
     assert (out - ref).abs().max().item() < 1e-2 * (1 + ref.abs().max().item())
 
 
+@pytest.mark.parametrize("I,J,K,epi", [(1024, 131584, 256, 1), (1024, 66000, 512, 2), (768, 87300, 128, 0)])
+def test_gemm_tile_counts_just_above_a_round(gpu_engine, I, J, K, epi):
+    """Tile counts just above a multiple of 256 (514 x 4 = 2056, ...): a last, nearly empty round of
+    the persistent kernel (or, with TVC_GEMM_SPLITK_TAIL=1, the split-K partial + finish kernels for the
+    left-over tile columns); every output row is compared, the tail rows separately."""
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    bias = torch.randn(I, device="cuda:0", generator=g) * 3.0
+    out = gpu_engine.gemm(a, b, bias, epi).float()
+    nIt = (I + 255) // 256
+    jt_full = ((nIt * ((J + 255) // 256)) // 256 * 256) // nIt
+    for lo, hi in ((0, jt_full * 256), (jt_full * 256, J)):
+        ref = b[lo:hi].float() @ a.float().t() + bias
+        if epi == 2:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        tol = (2e-4 if epi == 0 else 1e-2) * (1 + ref.abs().max().item())
+        assert (out[lo:hi] - ref).abs().max().item() < tol
+
+
 def test_gemm_identity_asymmetric(gpu_engine):
     """A = I with an asymmetric B catches a transposed accumulator map."""
     K = 256
@@ -130,9 +150,11 @@ def test_cosine_matrix(gpu_engine, pkg, N, M, D):
     assert (out.double().cpu() - ref).abs().max().item() < 1e-5
 
 
-def test_gemm_four_wave_variant_in_subprocess():
-    """TVC_GEMM_VARIANT=2 (read once per process) selects gemm_solo_kernel for the ring-eligible bf16
-    GEMMs: same outputs as the PyTorch restatement, including a ragged token remainder."""
+@pytest.mark.parametrize("env", [{"TVC_GEMM_VARIANT": "2"}, {"TVC_GEMM_SPLITK_TAIL": "1"}])
+def test_gemm_variants_in_subprocess(env):
+    """Env switches read once per process: TVC_GEMM_VARIANT=2 selects gemm_solo_kernel for the
+    ring-eligible bf16 GEMMs (incl. a ragged token remainder), TVC_GEMM_SPLITK_TAIL=1 the split-K tail
+    for left-over tile columns.  Same outputs as the PyTorch restatement."""
     import os
     import subprocess
     import sys
@@ -140,7 +162,8 @@ def test_gemm_four_wave_variant_in_subprocess():
 import torch, tvc_amd as pkg
 eng = pkg.TVCEngine()
 g = torch.Generator(device="cuda:0").manual_seed(11)
-for I, J, K, epi in ((1024, 2048, 1024, 1), (768, 3000, 640, 2), (3072, 12800, 768, 2), (256, 2304, 4096, 1)):
+for I, J, K, epi in ((1024, 2048, 1024, 1), (768, 3000, 640, 2), (3072, 12800, 768, 2), (256, 2304, 4096, 1),
+                     (1024, 131584, 256, 1), (1024, 66000, 512, 2)):
     a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
     bias = torch.randn(I, device="cuda:0", generator=g) * 3.0
@@ -152,7 +175,7 @@ for I, J, K, epi in ((1024, 2048, 1024, 1), (768, 3000, 640, 2), (3072, 12800, 7
     assert err < 1e-2 * (1 + ref.abs().max().item()), (I, J, K, epi, err)
 print("SOLO_OK")
 '''
-    env = dict(os.environ, TVC_GEMM_VARIANT="2")
+    env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SOLO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

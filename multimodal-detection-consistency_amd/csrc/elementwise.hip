@@ -17,7 +17,8 @@
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int64_t x_row_stride,
                                                         const int32_t* __restrict__ row_idx,
-                                                        const uint16_t* __restrict__ delta, int write_x,
+                                                        const uint16_t* __restrict__ delta,
+                                                        const uint16_t* __restrict__ delta2, int write_x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
                                                         uint16_t* __restrict__ y, int rows, int d) {
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
     const int64_t src_row = row_idx ? (int64_t)row_idx[row] : (int64_t)row;
     f32x4_t* xr = (f32x4_t*)(x + src_row * x_row_stride);
     const u32x2_t* dr = delta ? (const u32x2_t*)(delta + src_row * x_row_stride) : nullptr;   // same [rows, d] element offset as x
+    const u32x2_t* dr2 = delta2 ? (const u32x2_t*)(delta2 + src_row * x_row_stride) : nullptr;
     const int nv = d >> 2;
     f32x4_t v[4];
     float s = 0.f;
@@ -42,8 +44,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                 v[i][1] += __uint_as_float(dd[0] & 0xffff0000u);
                 v[i][2] += __uint_as_float(dd[1] << 16);
                 v[i][3] += __uint_as_float(dd[1] & 0xffff0000u);
-                if (write_x) xr[c] = v[i];
             }
+            if (dr2) {
+                const u32x2_t dd = dr2[c];
+                v[i][0] += __uint_as_float(dd[0] << 16);
+                v[i][1] += __uint_as_float(dd[0] & 0xffff0000u);
+                v[i][2] += __uint_as_float(dd[1] << 16);
+                v[i][3] += __uint_as_float(dd[1] & 0xffff0000u);
+            }
+            if (write_x && (dr || dr2)) xr[c] = v[i];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -81,12 +90,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream) {
+                            hipStream_t stream, const uint16_t* delta2) {
     if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, write_x,
-                       g, b, y, rows, d);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, delta2,
+                       write_x, g, b, y, rows, d);
     return hipGetLastError();
 }
 

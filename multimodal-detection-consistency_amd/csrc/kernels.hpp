@@ -26,10 +26,10 @@ struct GemmLaunch {
 hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 
 // ---- elementwise.hip
-// y = LN(x [+ delta]); with delta and write_x the sum is written back to x (residual stream)
+// y = LN(x [+ delta [+ delta2]]); with a delta and write_x the sum is written back to x (residual stream)
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream);
+                            hipStream_t stream, const uint16_t* delta2 = nullptr);
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream);
 hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,

@@ -18,8 +18,8 @@ thread_local std::string g_create_error;
 enum Slot {
     // tower workspaces exist twice (vision, text: + WS_TOWER_N) so that the two towers can run
     // concurrently on two streams
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_SPLITK, WS_TOWER_N,
-    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TSPLITK,
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_TOWER_N,
+    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK,
     WS_PATCH, WS_EOT, WS_STARTS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
@@ -141,18 +141,21 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
     uint16_t* H = (uint16_t*)h->ws[WS_H + wso].p;
     uint16_t* QKV = (uint16_t*)h->ws[WS_QKV + wso].p;
     uint16_t* MLP = (uint16_t*)h->ws[WS_MLP + wso].p;
-    uint16_t* D = (uint16_t*)h->ws[WS_DELTA + wso].p;
-    // The residual projections (attention out-proj, MLP fc2) are store-only GEMMs writing a bf16
-    // `delta`; the NEXT LayerNorm pass folds it into the fp32 residual stream X while it
-    // normalises (one streaming kernel at the HBM roofline instead of a read-modify-write
-    // epilogue inside an MFMA-bound kernel).  The last delta is left pending for the caller's
-    // final LayerNorm (ln_post / ln_final), which receives it through `pending_delta`.
-    const uint16_t* delta = nullptr;
+    uint16_t* D1 = (uint16_t*)h->ws[WS_DELTA + wso].p;     // attention out-proj output
+    uint16_t* D2 = (uint16_t*)h->ws[WS_DELTA2 + wso].p;    // MLP fc2 output
+    // The residual projections (attention out-proj, MLP fc2) are store-only GEMMs writing bf16
+    // deltas; LayerNorm passes fold them into the fp32 residual stream X while they normalise (a
+    // streaming kernel at the HBM roofline instead of a read-modify-write epilogue inside an
+    // MFMA-bound kernel).  X is rewritten ONCE per layer: ln_2 normalises X + D1 without storing
+    // it, the next ln_1 reads X + D1 + D2 (same fp32 sums, same order) and stores that.  The last
+    // layer's two deltas are left pending for the caller's final LayerNorm (ln_post / ln_final).
+    bool pending = false;
     for (int l = 0; l < a.layers; ++l) {
         const tvc_layer_weights& w = lw[l];
         {
-            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * (delta ? 12.0 : 6.0));
-            HIP_TRY(launch_layernorm(X, d, nullptr, delta, 1, w.ln1_g, w.ln1_b, H, rows, d, st));
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * (pending ? 14.0 : 6.0));
+            HIP_TRY(launch_layernorm(X, d, nullptr, pending ? D1 : nullptr, 1, w.ln1_g, w.ln1_b, H, rows, d, st,
+                                     pending ? D2 : nullptr));
         }
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -166,11 +169,11 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.bo; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
+        g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
-            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 12.0);
-            HIP_TRY(launch_layernorm(X, d, nullptr, D, 1, w.ln2_g, w.ln2_b, H, rows, d, st));
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 8.0);
+            HIP_TRY(launch_layernorm(X, d, nullptr, D1, 0, w.ln2_g, w.ln2_b, H, rows, d, st));
         }
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -178,9 +181,9 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
-        g.bias = w.b2; g.out = D; g.ldo = d; g.epilogue = TVC_EPI_BF16;
+        g.bias = w.b2; g.out = D2; g.ldo = d; g.epilogue = TVC_EPI_BF16;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
-        delta = D;
+        pending = true;
     }
     return TVC_OK;
 }
@@ -193,6 +196,7 @@ int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_
     if ((rc = ensure(h, (Slot)(WS_MLP + wso), (size_t)rows * a.mlp * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_CLS + wso), (size_t)n_seq * a.width * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_DELTA + wso), (size_t)rows * a.width * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_DELTA2 + wso), (size_t)rows * a.width * 2))) return rc;
     // fp32 partial tiles of the split-K tail (<= 256 partial tiles of 256 KiB), only worth having
     // when the GEMMs are big enough for the persistent kernel
     if (rows >= 256 * 128 && (rc = ensure(h, (Slot)(WS_SPLITK + wso), (size_t)256 * 256 * 256 * 4))) return rc;
@@ -294,9 +298,10 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, 0, st))) return rc;
         // ln_post on the class rows, projection, L2 norm
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
-        // ln_post on the class rows (row b*T), folding in the last layer's pending fc2 delta
+        // ln_post on the class rows (row b*T), folding in the last layer's two pending deltas
         HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr,
-                                 (const uint16_t*)h->ws[WS_DELTA].p, 0, h->vw.ln_post_g, h->vw.ln_post_b, Hc, n, d, st));
+                                 (const uint16_t*)h->ws[WS_DELTA].p, 0, h->vw.ln_post_g, h->vw.ln_post_b, Hc, n, d, st,
+                                 (const uint16_t*)h->ws[WS_DELTA2].p));
         g = GemmLaunch();
         g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
@@ -346,7 +351,8 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
         if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st))) return rc;
         uint16_t* Hc = (uint16_t*)h->ws[WS_TCLS].p;
         HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
-                                 h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st));
+                                 h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st,
+                                 (const uint16_t*)h->ws[WS_TDELTA2].p));
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;

@@ -58,7 +58,13 @@ void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* 
     const int64_t ns2 = (int64_t)keff * R / 2048;
     if (ns < ns2) ns = ns2;
     if (ns < 4096) ns = 4096;
-    if (ns > 65536) ns = 65536;
+    // cap: the pre-pass similarities [M, ns] fp32 stay under 8 GiB (ns = 262144 at M = 5120 keeps a
+    // 10 M-row bank at ~600 survivors per query; the old 65536 cap left ~2800 +- 25 % and overflowed
+    // the 128-entry lists / 6144-entry pool for some of 5120 queries)
+    int64_t ns_cap = ((int64_t)8 << 30) / ((int64_t)(M > 0 ? M : 1) * 4);
+    if (ns_cap > 262144) ns_cap = 262144;
+    if (ns_cap < 65536) ns_cap = 65536;
+    if (ns > ns_cap) ns = ns_cap;
     ns = (ns + 255) / 256 * 256;
     if (ns > R) ns = R;
     if (ns < 1) ns = 1;

@@ -87,3 +87,43 @@ def test_config1_scale_properties(pkg, b32):
     S = rows[:16].double() @ bank.double().t()
     v, ix = S.topk(5, dim=1)
     assert (s1[:16].double() - v).abs().max().item() < 1e-5 and torch.equal(i1[:16].long(), ix)
+
+
+def test_config3_bank_stage_at_full_size(pkg):
+    """BASELINE configs[3]: the 10 M-row bank stage at full size on one GPU (15.4 GB of bf16 rows,
+    M = 5120 query-side rows).  Size-independent properties: searching the bank as 8 row shards
+    (what 8 GPUs hold) + ``tvc_topk_merge`` is bit-identical to one search over all rows; planted
+    rows are found; a sample of rows agrees with an fp64 product computed in chunks."""
+    R, D, M, k, W = 10_000_000, 768, 5120, 5, 8
+    eng = pkg.TVCEngine()
+    bank = pkg.synth.make_bank(R, D, seed=7, device="cuda:0", dtype=torch.bfloat16)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    q = torch.randn((M, D), device="cuda:0", generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    planted = torch.randperm(R, device="cuda:0", generator=g)[:64]
+    bank[planted] = (q[:64] + 0.02 * torch.randn((64, D), device="cuda:0", generator=g)).to(torch.bfloat16)
+    eng.set_bank(bank)
+    fi, fs, _ = eng.bank_search(q, k, want_moments=False)
+    eng.bank_status()
+    assert torch.equal(fi[:64, 0].long(), planted) and (fs[:64, 0] > 0.8).all()
+    parts_i, parts_s = [], []
+    for w in range(W):
+        lo, hi = pkg.sharding.shard_bounds(R, W, w)
+        eng.set_bank(bank[lo:hi])
+        i, s, _ = eng.bank_search(q, k, idx_offset=lo, want_moments=False)
+        eng.bank_status()
+        parts_i.append(i); parts_s.append(s)
+    mi, ms, _, _ = eng.topk_merge(torch.stack(parts_i), torch.stack(parts_s))
+    assert torch.equal(mi, fi) and torch.equal(ms, fs)
+    # fp64 spot check of 8 rows, the bank taken 1 M rows at a time
+    rows = q[1000:1008].double()
+    best_v = torch.full((8, k), -2.0, dtype=torch.float64, device="cuda:0")
+    best_i = torch.zeros((8, k), dtype=torch.long, device="cuda:0")
+    for lo in range(0, R, 1_000_000):
+        S = rows @ bank[lo:lo + 1_000_000].double().t()
+        v, ix = torch.cat([best_v, S], 1).topk(k, dim=1)
+        cat_i = torch.cat([best_i, torch.arange(lo, lo + S.shape[1], device="cuda:0").expand(8, -1)], 1)
+        best_v, best_i = v, torch.gather(cat_i, 1, ix)
+    assert (fs[1000:1008].double() - best_v).abs().max().item() < 1e-5
+    assert torch.equal(fi[1000:1008].long(), best_i)
+    eng.close()

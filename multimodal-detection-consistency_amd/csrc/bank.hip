@@ -68,6 +68,16 @@ void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* 
     ns = (ns + 255) / 256 * 256;
     if (ns > R) ns = R;
     if (ns < 1) ns = 1;
+    // when the cap bites, keep the per-(chunk, query) lists short (<= ~24 expected, cap 128) by
+    // cutting the bank into more chunks instead
+    {
+        int64_t s_min = ((int64_t)keff * R + 24 * ns - 1) / (24 * ns);
+        if (s_min > nbt) s_min = nbt;
+        if (s < s_min) {
+            const int64_t tpc2 = (nbt + s_min - 1) / s_min;
+            s = (nbt + tpc2 - 1) / tpc2;
+        }
+    }
     *n_sample = (int)ns;
     *sample_stride = (int)(R / ns > 0 ? R / ns : 1);
     *S = (int)s;

@@ -26,15 +26,18 @@
 // The per-tile guards become compile-time true, so the 16-key tiles of a query block are
 // straight-line code and their LDS reads / MFMAs / exps interleave instead of running as MAXT
 // dependent chains separated by scalar branches.
-template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv,
+// NW: waves per workgroup.  4 everywhere: a 6-wave form for the 257-token vision case (17 query
+// blocks in 3 rounds instead of 5) needs 3 waves per SIMD = 168 VGPRs, spills 94 of them and runs
+// 3.5x slower (1201 vs 343 us) - the 17 score tiles of a query block want the 256-register budget.
+template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16_t* __restrict__ qkv,
                                                         uint16_t* __restrict__ out,
                                                         const int32_t* __restrict__ starts, int T_fixed,
                                                         int heads, int n_items, int k_bytes, int region_bytes) {
     // WPS waves cooperate on one (sequence, head) item; a workgroup holds 4 / WPS items,
     // each with its own K/V region in LDS.  Short text sequences use WPS = 1.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IPW = 4 / WPS;
+    constexpr int IPW = NW / WPS;
     const int width = heads * ATT_DH;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -238,23 +241,23 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     }
 }
 
-template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false>
+template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
                              int max_T, int heads, hipStream_t stream) {
     const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
     const int k_bytes = NT * 16 * ATT_KROW;
     const int region = k_bytes + NP * 32 * ATT_VROW;
-    constexpr int IPW = 4 / WPS;
+    constexpr int IPW = NW / WPS;
     const size_t lds = (size_t)region * IPW;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS, EXACT>,
+        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (st != hipSuccess) return st;
         attr_done = true;
     }
     const int n_items = n_seq * heads;
-    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT>), dim3((n_items + IPW - 1) / IPW), dim3(256), lds, stream,
+    hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>), dim3((n_items + IPW - 1) / IPW), dim3(NW * 64), lds, stream,
                        qkv, out, starts, T, heads, n_items, k_bytes, region);
     return hipGetLastError();
 }

@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--shard-bank", action="store_true",
                    help="BASELINE configs[3]: --bank-rows is the GLOBAL bank, row-sharded over the ranks; "
                         "partial top-k lists are exchanged with RCCL (all-gather + all-to-all) and merged on the GPU")
+    p.add_argument("--rehearse-one-gpu", action="store_true",
+                   help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the process group is "
+                        "gloo (RCCL refuses two ranks on one device); checks the launch contract, not speed")
     p.add_argument("--serial-towers", action="store_true",
                    help="encode text then images on ONE stream (default: two streams, the towers overlap)")
     p.add_argument("--chunk-images", type=int, default=0, help="images per tower pass (0 = library default)")
@@ -100,12 +103,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or a.shard_bank:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if a.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     arch = pkg.get_arch(a.model)
     B, N, R, D = a.batch, a.variants, a.bank_rows, arch.embed_dim
@@ -172,7 +180,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if a.rehearse_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     eng.bank_status()

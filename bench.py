@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--serial-towers", action="store_true",
                    help="encode text then images on ONE stream (default: two streams, the towers overlap)")
     p.add_argument("--chunk-images", type=int, default=0, help="images per tower pass (0 = library default)")
+    p.add_argument("--no-prefix-sharing", action="store_true",
+                   help="encode every variant in full (default: variants share the rows of the token prefix they have "
+                        "in common with their original - bit-identical, see TVC_OPT_TEXT_GROUP)")
     p.add_argument("--dense-text", action="store_true",
                    help="run the text tower on all 77 positions (disable EOT packing)")
     return p.parse_args()
@@ -139,7 +142,7 @@ def main():
 
     def step(serial=False):
         if a.serial_towers or serial:
-            ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))   # first: its one row-count read-back
+            ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx), group=0 if a.no_prefix_sharing else N + 1)   # first: its one row-count read-back
             fi = eng.encode_image(images)                               # happens while the GPU is still idle
         else:
             # The towers are independent until the bank search: run them on two streams.  The HBM-bound
@@ -148,7 +151,7 @@ def main():
             main = torch.cuda.current_stream()
             s_txt.wait_stream(main); s_img.wait_stream(main)
             with torch.cuda.stream(s_txt):
-                ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))
+                ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx), group=0 if a.no_prefix_sharing else N + 1)
             with torch.cuda.stream(s_img):
                 fi = eng.encode_image(images)
             main.wait_stream(s_txt); main.wait_stream(s_img)
@@ -236,7 +239,7 @@ def main():
                                    f"encode + exact top-{k} bank search + consistency (BASELINE configs[2])",
                        "global_batch": world * B, "parallelism": (f"dp{world} queries x bank rows sharded {world}-way (RCCL all-gather + all-to-all of partial top-k)"
                                        if a.shard_bank else f"dp{world}"),
-                       "text_packing": "dense-77" if a.dense_text else "eot-packed (bit-identical, see DESIGN.md)",
+                       "text_packing": "dense-77" if a.dense_text else ("eot-packed" + ("" if a.no_prefix_sharing else " + variant prefix sharing") + " (bit-identical, see DESIGN.md)"),
                        "algorithmic_gflop_per_query_dense": round(flops_q / 1e9, 2),
                        "executed_gflop_per_query": round(exec_flops / B / 1e9, 2) if exec_flops else None,
                        "executed_path_tflops": round(qps * exec_flops / B / 1e12, 1) if exec_flops else None},

@@ -126,9 +126,15 @@ const char* tvc_last_error(tvc_handle* h);
  * similarity could exceed the running bound (Cauchy-Schwarz margin from the bank's
  * largest row norms) and re-scores the kept rows in fp32: the same top-k set, values at
  * least as accurate, 1/2 (bf16 bank) or 1/3 (fp32 bank) of the matrix-core work.  0 forces
- * the all-products pass. */
+ * the all-products pass.
+ * TVC_OPT_TEXT_GROUP (default 0 = off): G >= 2 declares that the rows passed to tvc_encode_text
+ * come in consecutive groups of G texts whose first text is the original and the others its
+ * variants (the layout of pipeline.detect: original + N variants).  A causal tower gives two texts
+ * identical hidden states on their common token prefix, so a variant keeps only the rows from its
+ * first differing token on and attends to the original's rows for the shared prefix.  Outputs are
+ * bit-identical; needs text packing and T % G == 0, otherwise it is ignored for that call. */
 enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
-       TVC_OPT_BANK_FILTER = 4 };
+       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
 
 /* Bytes of device workspace currently held by the handle. */

@@ -19,6 +19,7 @@ TVC_OK, TVC_E_INVALID, TVC_E_HIP, TVC_E_NOMEM, TVC_E_STATE, TVC_E_OVERFLOW = ran
 TVC_DTYPE_BF16, TVC_DTYPE_F32 = 0, 1
 TVC_REC_HEAD, TVC_REC_MAXREF = 12, 16
 TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS, TVC_OPT_BANK_FILTER = 1, 2, 3, 4
+TVC_OPT_TEXT_GROUP = 5
 
 
 class TVCError(RuntimeError):

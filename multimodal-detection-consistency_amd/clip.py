@@ -197,10 +197,11 @@ class CLIPModel:
             raise NotImplementedError("backward through the HIP towers is out of scope (attacks only, SURVEY.md 8f)")
         return self.encode_image(x)
 
-    def encode_tokens(self, tokens: torch.Tensor, normalize: Optional[bool] = None) -> torch.Tensor:
-        """int [T, ctx] -> device tensor [T, D]."""
+    def encode_tokens(self, tokens: torch.Tensor, normalize: Optional[bool] = None, group: int = 0) -> torch.Tensor:
+        """int [T, ctx] -> device tensor [T, D].  ``group`` = N + 1 when the rows are consecutive
+        (original, N variants) groups (see ``TVCEngine.encode_text``)."""
         normalize = self.config.normalize if normalize is None else normalize
-        return self.engine.encode_text(tokens.to(self.device, torch.int32), normalize)
+        return self.engine.encode_text(tokens.to(self.device, torch.int32), normalize, group=group)
 
     def encode_text(self, texts: Union[str, Sequence[str], torch.Tensor], normalize: Optional[bool] = None) -> torch.Tensor:
         """list[str] -> CPU tensor [B, D] (src/retrieval.py:551-554 calls ``.numpy()``);

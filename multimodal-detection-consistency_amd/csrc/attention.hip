@@ -33,7 +33,8 @@ template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16_t* __restrict__ qkv,
                                                         uint16_t* __restrict__ out,
                                                         const int32_t* __restrict__ starts, int T_fixed,
-                                                        int heads, int n_items, int k_bytes, int region_bytes) {
+                                                        int heads, int n_items, int k_bytes, int region_bytes,
+                                                        const int32_t* __restrict__ pfx, int n_seq) {
     // WPS waves cooperate on one (sequence, head) item; a workgroup holds 4 / WPS items,
     // each with its own K/V region in LDS.  Short text sequences use WPS = 1.
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,13 +50,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     const bool active = item < n_items;
     if (!active) item = n_items - 1;
     const int seq = item / heads, h = item - seq * heads;
-    int64_t row0;
-    int T;
+    int64_t row0;      // first of the sequence's own rows
+    int T;             // keys: P shared-prefix rows (from prow0) + the own rows
+    int P = 0;         // shared prefix length: queries are the own rows only (positions P .. T-1)
+    int64_t prow0 = 0;
     if (starts) {
         const int s0 = __builtin_amdgcn_readfirstlane(starts[seq]);
         const int s1 = __builtin_amdgcn_readfirstlane(starts[seq + 1]);
         row0 = s0; T = s1 - s0;
+        if (CAUSAL && pfx) {
+            P = __builtin_amdgcn_readfirstlane(pfx[seq]);
+            prow0 = __builtin_amdgcn_readfirstlane(pfx[n_seq + seq]);
+            T += P;
+        }
     } else { row0 = (int64_t)seq * T_fixed; T = T_fixed; }
+    // packed row of key / position t
+    auto key_row = [&](int t) -> int64_t { return t < P ? prow0 + t : row0 + (t - P); };
     if (T > MAXT * 16) T = MAXT * 16;      // host guarantees this; never index past the region
     const int NT = EXACT ? MAXT : (T + 15) >> 4;          // key tiles of 16
     const int NP = (NT + 1) >> 1;          // key pairs of 32
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
             kv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) kv[i] = *(const u32x4_t*)(qkv + (row0 + key) * ld + width + h * ATT_DH + c * 8);
+            if (key < T) kv[i] = *(const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
             vv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) vv[i] = *(const u32x4_t*)(qkv + (row0 + key) * ld + 2 * width + h * ATT_DH + c * 8);
+            if (key < T) vv[i] = *(const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
@@ -112,7 +122,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     // columns 4*(i&3) .. +3 of a [4 keys][16 dh] block
     const int tr_off = (4 * g + (r16 >> 2)) * ATT_VROW + ((r16 & 3) << 3);
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // dh^-0.5 * log2(e)
-    const int NQ = NT;
+    const int own = T - P;                     // query rows (all of them unless a prefix is shared)
+    const int NQ = (own + 15) >> 4;
     // Masking costs nothing after the MFMA: the accumulator is INITIALISED with 0 or -inf
     // (-inf + q.k = -inf).  Only the last key tile holds keys >= T.
     f32x4_t pen_tail;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     // Q fragments come straight from HBM/L2: fetch the NEXT block's while this one computes
     auto q_ptr = [&](int qb) {
         int qrow = qb * 16 + r16;
-        qrow = qrow < T ? qrow : T - 1;
+        qrow = qrow < own ? qrow : own - 1;
         return qkv + (row0 + qrow) * ld + h * ATT_DH + 8 * g;
     };
     bf16x8_t nq0 = {}, nq1 = {};
@@ -132,7 +143,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         const int qr = qb * 16 + r16;
         const bf16x8_t bq0 = nq0, bq1 = nq1;
         if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
-        const int nt_q = EXACT ? MAXT : (CAUSAL ? ((qb + 1 < NT) ? qb + 1 : NT) : NT);
+        // causal: keys up to the block's last query position P + qb*16 + 15
+        const int nt_c = ((P + qb * 16 + 15) >> 4) + 1;
+        const int nt_q = EXACT ? MAXT : (CAUSAL ? (nt_c < NT ? nt_c : NT) : NT);
 
         f32x4_t s[MAXT];
         float mx = -INFINITY;          // max of the RAW scores (scaling by a positive constant is monotonic)
@@ -163,10 +176,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (t < nt_q) {
                 f32x4_t c0 = (t == NT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (CAUSAL && t == qb) {
+                if (CAUSAL && t * 16 + 15 > P + qb * 16) {      // tile reaches past the block's first query position
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (t * 16 + 4 * g + r > qr) c0[r] = -INFINITY;
+                        if (t * 16 + 4 * g + r > P + qr) c0[r] = -INFINITY;
                 }
                 const char* kr = ldsK + (t * 16 + r16) * ATT_KROW;
                 const bf16x8_t a0 = *(const bf16x8_t*)(kr + sw0);
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 }
             }
         }
-        if (qr < T) {
+        if (qr < own) {
             const float inv = 1.0f / lsum;
             uint16_t* op = out + (row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;
 #pragma unroll
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
 
 template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
-                             int max_T, int heads, hipStream_t stream) {
+                             int max_T, int heads, hipStream_t stream, const int32_t* pfx = nullptr) {
     const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
     const int k_bytes = NT * 16 * ATT_KROW;
     const int region = k_bytes + NP * 32 * ATT_VROW;
@@ -258,21 +271,22 @@ static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* 
     }
     const int n_items = n_seq * heads;
     hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>), dim3((n_items + IPW - 1) / IPW), dim3(NW * 64), lds, stream,
-                       qkv, out, starts, T, heads, n_items, k_bytes, region);
+                       qkv, out, starts, T, heads, n_items, k_bytes, region, pfx, n_seq);
     return hipGetLastError();
 }
 
 // starts == nullptr: n_seq sequences of seq_len rows each; otherwise sequence s owns rows
 // [starts[s], starts[s+1]) (device array of n_seq + 1 ints) and seq_len is the MAXIMUM length.
 hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len,
-                            int heads, int causal, hipStream_t stream) {
+                            int heads, int causal, hipStream_t stream, const int32_t* pfx) {
     if (n_seq <= 0) return hipSuccess;
     if (seq_len < 1 || seq_len > 288 || heads < 1) return hipErrorInvalidValue;
     const int NT = (seq_len + 15) / 16;
     if (causal) {
-        if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
-        if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
-        return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+        if (pfx && !starts) return hipErrorInvalidValue;
+        if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
+        if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
+        return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
     }
     if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);   // ViT-L/14: 257 tokens
     if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);     // ViT-B/32: 50 tokens

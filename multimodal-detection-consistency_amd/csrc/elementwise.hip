@@ -226,8 +226,13 @@ hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const
 // starts = exclusive scan, starts[n_text] = total rows, starts[n_text+1] = max len.
 // One workgroup; n_text is a few thousand.
 // ---------------------------------------------------------------------------
+// Prefix sharing (pfx != nullptr, texts in consecutive groups of G, first of a group = base text): a
+// causal tower gives two texts identical hidden states on their common prefix, so text n keeps only
+// the rows from its first token that differs from the base text on: starts[] then scans the OWN row
+// counts, pfx[n] = shared prefix length, pfx[n_text + n] = packed row of the base text's position 0.
 __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __restrict__ tok,
-                                                               int32_t* __restrict__ starts, int n_text, int ctx) {
+                                                               int32_t* __restrict__ starts,
+                                                               int32_t* __restrict__ pfx, int n_text, int ctx, int G) {
     __shared__ int part[1024];
     __shared__ int carry_s;
     __shared__ int maxlen_s;
@@ -250,7 +255,32 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
                 const int ot = __shfl_xor(best_t, o, 64);
                 if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
             }
-            if (lane == 0) starts[n] = best_t + 1;
+            int len = best_t + 1, p = 0;
+            if (pfx) {
+                const int bn = n / G * G;
+                if (bn != n) {
+                    // length of the base text, then the first position where the two differ
+                    int bb = -1, bt = 0, mis = 0x7fffffff;
+                    for (int tt = lane; tt < ctx; tt += 64) {
+                        const int vb = tok[(int64_t)bn * ctx + tt], vn = tok[(int64_t)n * ctx + tt];
+                        if (vb > bb) { bb = vb; bt = tt; }
+                        if (vb != vn && tt < mis) mis = tt;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const int ov = __shfl_xor(bb, o, 64);
+                        const int ot = __shfl_xor(bt, o, 64);
+                        if (ov > bb || (ov == bb && ot < bt)) { bb = ov; bt = ot; }
+                        const int om = __shfl_xor(mis, o, 64);
+                        mis = om < mis ? om : mis;
+                    }
+                    p = mis;
+                    if (p > len) p = len;
+                    if (p > bt + 1) p = bt + 1;
+                }
+                if (lane == 0) { pfx[n] = p; pfx[n_text + n] = len; }      // [n_text + n]: len parked for phase B
+            }
+            if (lane == 0) starts[n] = len - p;
         }
     }
     __syncthreads();
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
         int len = 0;
         if (n < n_text) {
             len = starts[n];
-            atomicMax(&maxlen_s, len);
+            atomicMax(&maxlen_s, pfx ? pfx[n_text + n] : len);      // attention length = prefix + own rows
         }
         part[t] = len;
         __syncthreads();
@@ -276,10 +306,16 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
         __syncthreads();
     }
     if (t == 0) { starts[n_text] = carry_s; starts[n_text + 1] = maxlen_s; }
+    if (pfx) {
+        __syncthreads();
+        for (int n = t; n < n_text; n += 1024) pfx[n_text + n] = starts[n / G * G];
+    }
 }
 
-hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int n_text, int ctx, hipStream_t stream) {
-    hipLaunchKernelGGL(text_lens_scan_kernel, dim3(1), dim3(1024), 0, stream, tok, starts, n_text, ctx);
+hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int32_t* pfx, int n_text, int ctx, int G,
+                                 hipStream_t stream) {
+    if (pfx && G < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(text_lens_scan_kernel, dim3(1), dim3(1024), 0, stream, tok, starts, pfx, n_text, ctx, G);
     return hipGetLastError();
 }
 
@@ -294,7 +330,8 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
                                                          const float* __restrict__ pos,
                                                          float* __restrict__ x,
                                                          int32_t* __restrict__ eot_row,
-                                                         const int32_t* __restrict__ starts, int n_text,
+                                                         const int32_t* __restrict__ starts,
+                                                         const int32_t* __restrict__ pfx, int n_text,
                                                          int ctx, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -303,10 +340,12 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     const int64_t n = row / ctx;
     int64_t out_row = row;
     if (starts) {
-        const int s0 = starts[n], len = starts[n + 1] - s0;
-        if (t >= len) return;
-        out_row = s0 + t;
-        if (t == 0 && lane == 0) eot_row[n] = s0 + len - 1;
+        const int s0 = starts[n], own = starts[n + 1] - s0;
+        const int p = pfx ? pfx[n] : 0;
+        // the EOT row: the last own row, or (text identical to its base up to EOT) the base's row
+        if (t == 0 && lane == 0) eot_row[n] = own > 0 ? s0 + own - 1 : pfx[n_text + n] + p - 1;
+        if (t < p || t >= p + own) return;
+        out_row = s0 + (t - p);
     }
     int id = tok[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -333,13 +372,13 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
 
 hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
                              int32_t* eot_row, const int32_t* starts, int n_text, int ctx, int d, int vocab,
-                             hipStream_t stream) {
+                             hipStream_t stream, const int32_t* pfx) {
     if (d % 4 != 0) return hipErrorInvalidValue;
     const int64_t rows = (int64_t)n_text * ctx;
     if (rows == 0) return hipSuccess;
     const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     hipLaunchKernelGGL(text_embed_kernel, dim3(grid), dim3(256), 0, stream, tok, tok_emb, pos, x, eot_row, starts,
-                       n_text, ctx, d, vocab);
+                       pfx, n_text, ctx, d, vocab);
     return hipGetLastError();
 }
 

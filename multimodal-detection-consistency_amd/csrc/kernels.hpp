@@ -37,11 +37,15 @@ hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const
                                  hipStream_t stream);
 // starts == nullptr: dense [n_text, ctx] rows; else packed rows (text n owns rows
 // [starts[n], starts[n+1]), i.e. its tokens up to and including EOT)
+// pfx (optional, with starts): prefix sharing - text n owns only the rows of positions >= pfx[n]; see
+// text_lens_scan_kernel
 hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const float* pos, float* x,
                              int32_t* eot_row, const int32_t* starts, int n_text, int ctx, int d, int vocab,
-                             hipStream_t stream);
-// starts[0..n_text] = exclusive scan of (argmax position + 1); starts[n_text + 1] = max length
-hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int n_text, int ctx,
+                             hipStream_t stream, const int32_t* pfx = nullptr);
+// starts[0..n_text] = exclusive scan of the own row counts (argmax position + 1 [- shared prefix]);
+// starts[n_text + 1] = max length; pfx (optional, int32 [2 * n_text], groups of G texts): [n] = shared
+// prefix length, [n_text + n] = packed row of the base text's position 0
+hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int32_t* pfx, int n_text, int ctx, int G,
                                  hipStream_t stream);
 hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream);
 hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
@@ -51,8 +55,10 @@ hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int 
                               hipStream_t stream);
 
 // ---- attention.hip
+// pfx (optional, causal packed rows only): sequence s = pfx[s] rows starting at packed row
+// pfx[n_seq + s] (shared prefix, keys only) followed by its own rows [starts[s], starts[s+1]) (keys + queries)
 hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq,
-                            int seq_len, int heads, int causal, hipStream_t stream);
+                            int seq_len, int heads, int causal, hipStream_t stream, const int32_t* pfx = nullptr);
 
 // ---- bank.hip
 struct BankSearchLaunch {

@@ -20,7 +20,7 @@ enum Slot {
     // concurrently on two streams
     WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_TOWER_N,
     WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK,
-    WS_PATCH, WS_EOT, WS_STARTS,
+    WS_PATCH, WS_EOT, WS_STARTS, WS_PFX,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
     WS_COUNT
@@ -58,6 +58,7 @@ struct tvc_handle {
     int max_chunk_images = 512;
     int max_chunk_texts = 4608;
     bool pack_text = true;     // TVC_OPT_TEXT_PACKING
+    int text_group = 0;        // TVC_OPT_TEXT_GROUP: texts come in groups of this many sharing prefixes (0: off)
     bool prof = false;
     std::vector<ProfRec> prof_recs;
 };
@@ -134,7 +135,8 @@ bool tower_ok(const tvc_tower_arch& a) {
 // Sequences: n_seq x seq_len dense rows, or (starts != nullptr) packed rows with
 // `total_rows` rows in all and seq_len = the maximum length.
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
-               int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st) {
+               int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st,
+               const int32_t* pfx = nullptr) {
     const int d = a.width;
     const int rows = starts ? total_rows : n_seq * seq_len;
     float* X = (float*)h->ws[WS_X + wso].p;
@@ -165,7 +167,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
             const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
             const double fl = 4.0 * n_seq * a.heads * avg_len * avg_len * 64 * (causal ? 0.5 : 1.0);
             ProfScope ps(h, st, TVC_PROF_ATTENTION, fl);
-            HIP_TRY(launch_attention(QKV, H, starts, n_seq, seq_len, a.heads, causal, st));
+            HIP_TRY(launch_attention(QKV, H, starts, n_seq, seq_len, a.heads, causal, st, pfx));
         }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
@@ -321,9 +323,14 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     const tvc_tower_arch& a = m.text;
     const int d = a.width, ctx = m.ctx;
     if (Tn == 0) return TVC_OK;
-    const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
+    int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
+    // prefix sharing needs whole groups in a pass
+    const int G = (h->pack_text && h->text_group >= 2 && Tn % h->text_group == 0) ? h->text_group : 0;
+    if (G && chunk >= G) chunk = chunk / G * G;
+    const bool share = G && chunk % G == 0;
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk, WS_TOWER_N))) return rc;
+    if (share && (rc = ensure(h, WS_PFX, (size_t)chunk * 2 * 4))) return rc;
     if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
     if ((rc = ensure(h, WS_STARTS, (size_t)(chunk + 2) * 4))) return rc;
     for (int t0 = 0; t0 < Tn; t0 += chunk) {
@@ -331,24 +338,27 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
         int32_t* eot = (int32_t*)h->ws[WS_EOT].p;
         const int32_t* tok = tok_dev + (size_t)t0 * ctx;
         const int32_t* starts = nullptr;
+        const int32_t* pfx = nullptr;
         int total_rows = n * ctx, max_len = ctx;
         if (h->pack_text) {
             // Keep only the tokens up to and including EOT: under the causal mask the later
             // positions cannot reach the pooled (EOT) row, so the result is bit-identical.
             // The row count sizes the GEMM grids, hence ONE 8-byte read-back per call.
             int32_t* sd = (int32_t*)h->ws[WS_STARTS].p;
-            HIP_TRY(launch_text_lens_scan(tok, sd, n, ctx, st));
+            int32_t* pd = share ? (int32_t*)h->ws[WS_PFX].p : nullptr;
+            HIP_TRY(launch_text_lens_scan(tok, sd, pd, n, ctx, G, st));
+            pfx = pd;
             int32_t tail[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(tail, sd + n, sizeof tail, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             total_rows = tail[0]; max_len = tail[1];
-            if (total_rows < n || total_rows > n * ctx || max_len < 1 || max_len > ctx)
+            if (total_rows < (share ? n / G : n) || total_rows > n * ctx || max_len < 1 || max_len > ctx)
                 return fail(h, TVC_E_HIP, "tvc_encode_text: inconsistent sequence lengths");
             starts = sd;
         }
         HIP_TRY(launch_text_embed(tok, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_TX].p, eot, starts, n, ctx, d,
-                                  m.vocab, st));
-        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st))) return rc;
+                                  m.vocab, st, pfx));
+        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st, pfx))) return rc;
         uint16_t* Hc = (uint16_t*)h->ws[WS_TCLS].p;
         HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
                                  h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st,
@@ -562,6 +572,9 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
     switch (option) {
         case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
         case TVC_OPT_BANK_FILTER: h->bank_filter = value != 0; return TVC_OK;
+        case TVC_OPT_TEXT_GROUP:
+            if (value < 0 || value > 4096) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TEXT_GROUP out of range");
+            h->text_group = (int)value; return TVC_OK;
         case TVC_OPT_MAX_CHUNK_IMAGES:
             if (value < 1) return fail(h, TVC_E_INVALID, "tvc_set_option: chunk must be >= 1");
             h->max_chunk_images = (int)value; return TVC_OK;

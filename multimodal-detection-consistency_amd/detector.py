@@ -135,7 +135,7 @@ class AdversarialDetector:
         clip = self._get_clip_model()
         B, N1, ctx = tokens.shape
         fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
-        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True)
+        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True, group=N1)
         rec = clip.engine.consistency(fi, ft.view(B, N1, -1), ConsistencyConfig())
         out = unpack_records(rec, N1 - 1)
         out["aggregated_score"] = out["score_src"]
@@ -169,7 +169,7 @@ class AdversarialDetector:
                 flat.append(texts[i])
                 flat.extend(variants[i])
             tok = clip.tokenize(flat)
-            ft = clip.encode_tokens(tok, True).view(len(ids), N + 1, -1)
+            ft = clip.encode_tokens(tok, True, group=N + 1).view(len(ids), N + 1, -1)
             sel = torch.as_tensor(ids, device=fi.device)
             rec = unpack_records(clip.engine.consistency(fi[sel].contiguous(), ft, ConsistencyConfig()), N)
             for j, i in enumerate(ids):
@@ -405,7 +405,7 @@ class MultiModalDefenseDetector:
         clip = self.clip_model
         B, N1, ctx = tokens.shape
         fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
-        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True)
+        ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True, group=N1)
         use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
         rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank, robust=True)
         return unpack_records(rec, N1 - 1)
@@ -444,7 +444,7 @@ class MultiModalDefenseDetector:
             for i in ids:
                 flat.append(texts[i])
                 flat.extend(variants[i])
-            ft = clip.encode_tokens(clip.tokenize(flat), True).view(len(ids), N + 1, -1)
+            ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
             sel = torch.as_tensor(ids, device=fi.device)
             rec = unpack_records(clip.engine.detect_embeddings(fi[sel].contiguous(), ft, self._cons_cfg(), use_bank,
                                                                robust=True), N)

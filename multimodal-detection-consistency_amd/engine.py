@@ -155,16 +155,25 @@ class TVCEngine:
                                                   int(normalize), _stream()))
         return out
 
-    def encode_text(self, tokens: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-        """tokens int [T, ctx] (on the GPU) -> fp32 [T, D]."""
+    def encode_text(self, tokens: torch.Tensor, normalize: bool = True, group: int = 0) -> torch.Tensor:
+        """tokens int [T, ctx] (on the GPU) -> fp32 [T, D].  ``group`` = N + 1 declares that the rows
+        are consecutive (original, variant_1 .. variant_N) groups: variants then share the rows of
+        the token prefix they have in common with their original (``TVC_OPT_TEXT_GROUP``; the
+        embeddings are bit-identical, the text tower does less work)."""
         a = self.arch
         if tokens.dim() != 2 or tokens.shape[1] != a.ctx:
             raise ValueError(f"expected [T, {a.ctx}] token ids, got {tuple(tokens.shape)}")
         tokens = _require_cuda(tokens, torch.int32, "tokens")
         out = torch.empty((tokens.shape[0], a.embed_dim), dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.tvc_encode_text(self.handle, _ptr(tokens), tokens.shape[0], _ptr(out),
-                                                 int(normalize), _stream()))
+            if group >= 2:
+                self._check(self.lib.tvc_set_option(self.handle, _lib.TVC_OPT_TEXT_GROUP, int(group)))
+            try:
+                self._check(self.lib.tvc_encode_text(self.handle, _ptr(tokens), tokens.shape[0], _ptr(out),
+                                                     int(normalize), _stream()))
+            finally:
+                if group >= 2:
+                    self._check(self.lib.tvc_set_option(self.handle, _lib.TVC_OPT_TEXT_GROUP, 0))
         return out
 
     # ---- bank ----------------------------------------------------------

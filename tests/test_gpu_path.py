@@ -255,6 +255,35 @@ def test_text_packing_is_bit_identical(pkg):
     eng.close()
 
 
+@pytest.mark.parametrize("model,ctx_lens", [("ViT-T/16-test", (1, 75)), ("ViT-L/14", (5, 20))])
+def test_text_prefix_sharing_is_bit_identical(pkg, model, ctx_lens):
+    """TVC_OPT_TEXT_GROUP = N+1: a variant keeps only the rows from its first token that differs from
+    the group's original on (the causal tower gives the shared prefix identical hidden states) and
+    attends to the original's rows for the prefix.  Same embeddings bit for bit, including variants
+    identical to the original, differing right after SOT, or longer / shorter than it."""
+    arch = pkg.get_arch(model)
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, None, tw)
+    Q, N = (24, 3) if model != "ViT-L/14" else (64, 8)
+    toks = pkg.synth.make_tokens(Q, N, arch.ctx, seed=6, min_len=ctx_lens[0], max_len=ctx_lens[1])
+    toks[1, 2] = toks[1, 0]                                        # variant identical to its original
+    toks[2, 1, 1] = 777                                            # differs right after SOT
+    L = int(toks[3, 0].argmax())
+    if L + 2 < arch.ctx:
+        toks[3, 1, L] = 55; toks[3, 1, L + 1] = 49407              # one token longer than the original
+    if L > 2:
+        toks[3, 2] = 0; toks[3, 2, :L - 1] = toks[3, 0, :L - 1]; toks[3, 2, L - 1] = 49407   # one token shorter
+    flat = toks.reshape(-1, arch.ctx).cuda()
+    plain = eng.encode_text(flat).cpu()
+    ws0 = eng.workspace_bytes()
+    eng.set_option(pkg._lib.TVC_OPT_TEXT_GROUP, N + 1)
+    shared = eng.encode_text(flat).cpu()
+    assert torch.equal(shared, plain)
+    # a batch that is not a whole number of groups silently falls back to the plain packed path
+    assert torch.equal(eng.encode_text(flat[:-1]).cpu(), plain[:-1])
+    eng.close()
+
+
 def test_two_shard_search_equals_full_search(gpu_engine):
     """The bank-sharded path on one GPU: search each half with its global row offset,
     gather the winners' rows, merge with tvc_topk_merge -> identical to searching the

@@ -403,6 +403,42 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         }
         return hipGetLastError();
     }
+    // ---- few tiles, deep K (small batches): one tile per workgroup would leave most of the 256 CUs idle
+    // and run K serially (FC2 at one image: 8 workgroups x 64 K-steps).  Split K over S workgroups per
+    // tile (fp32 partial tiles + the finish kernel of the split-K tail above).
+    {
+        // Opt-in (TVC_GEMM_SPLITK_SMALL=1, a latency mode: one query 7.5 -> 5.3 ms): the fp32 sums are taken
+        // in a different order than in the one-pass kernels, so a query's embedding would depend (in the
+        // last bits) on the size of the batch it arrives in; by default it does not
+        // (tests/test_gpu_configs.py::test_config1_scale_properties, batch-split invariance).
+        static const bool small_on = [] { const char* v = getenv("TVC_GEMM_SPLITK_SMALL"); return v && atoi(v) != 0; }();
+        const int nk64 = (int)((int64_t)L.K * L.planes / GEMM_BK);
+        int S = ntiles > 0 ? 256 / ntiles : 0;
+        if (S > nk64 / 2) S = nk64 / 2;
+        if (S > 16) S = 16;
+        if (small_on && forced < 0 && L.splitk_ws && S >= 2 &&
+            (size_t)ntiles * S * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes) {
+            hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(ntiles * S), block, GEMM_LDS_BYTES, stream, g,
+                               L.splitk_ws, nIt, 0, S);
+            switch (L.epilogue) {
+                case TVC_EPI_F32:
+                    hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_F32>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                    break;
+                case TVC_EPI_BF16:
+                    hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_BF16>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                    break;
+                case TVC_EPI_GELU_BF16:
+                    hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_GELU_BF16>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                    break;
+                case TVC_EPI_RESID_F32:
+                    hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_RESID_F32>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                    break;
+                default:
+                    return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     const dim3 grid(nIt * nJt);
     switch (L.epilogue) {
         case TVC_EPI_F32:

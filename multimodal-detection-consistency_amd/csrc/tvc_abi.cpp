@@ -199,9 +199,9 @@ int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_
     if ((rc = ensure(h, (Slot)(WS_CLS + wso), (size_t)n_seq * a.width * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_DELTA + wso), (size_t)rows * a.width * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_DELTA2 + wso), (size_t)rows * a.width * 2))) return rc;
-    // fp32 partial tiles of the split-K tail (<= 256 partial tiles of 256 KiB), only worth having
-    // when the GEMMs are big enough for the persistent kernel
-    if (rows >= 256 * 128 && (rc = ensure(h, (Slot)(WS_SPLITK + wso), (size_t)256 * 256 * 256 * 4))) return rc;
+    // fp32 partial tiles of the split-K paths (<= 256 partial tiles of 256 KiB): small batches split
+    // every tile over K, big ones (opt-in) the left-over tile columns
+    if ((rc = ensure(h, (Slot)(WS_SPLITK + wso), (size_t)256 * 256 * 256 * 4))) return rc;
     return TVC_OK;
 }
 
@@ -294,7 +294,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         GemmLaunch g;
         g.A = h->vw.patch_w; g.lda = Kp; g.I = d; g.B = Pm; g.ldb = Kp; g.J = n * P; g.K = Kp;
         g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));
         if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, 0, st))) return rc;
@@ -307,7 +307,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         g = GemmLaunch();
         g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
         if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)b0 * m.embed_dim, n, m.embed_dim, st));
     }
     return TVC_OK;
@@ -366,7 +366,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
-        HIP_TRY(timed_gemm(h, g, st));
+        HIP_TRY(timed_gemm(h, g, st, WS_TSPLITK));
         if (normalize) HIP_TRY(launch_l2norm_rows(out_dev + (size_t)t0 * m.embed_dim, n, m.embed_dim, st));
     }
     return TVC_OK;
@@ -619,8 +619,8 @@ int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev, c
     GemmLaunch g;
     g.A = a_dev; g.lda = K; g.I = I; g.B = b_dev; g.ldb = K; g.J = J; g.K = K;
     g.bias = bias_dev; g.out = out_dev; g.ldo = ld_out; g.epilogue = epilogue;
-    if ((int64_t)((I + 255) / 256) * ((J + 255) / 256) >= 512) {       // persistent-kernel sizes: split-K tail scratch
-        int rc = ensure(h, WS_SPLITK, (size_t)256 * 256 * 256 * 4);
+    {
+        int rc = ensure(h, WS_SPLITK, (size_t)256 * 256 * 256 * 4);       // split-K scratch (small or tail tiles)
         if (rc) return rc;
         g.splitk_ws = (float*)h->ws[WS_SPLITK].p; g.splitk_ws_bytes = h->ws[WS_SPLITK].n;
     }

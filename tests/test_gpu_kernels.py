@@ -150,11 +150,12 @@ def test_cosine_matrix(gpu_engine, pkg, N, M, D):
     assert (out.double().cpu() - ref).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("env", [{"TVC_GEMM_VARIANT": "2"}, {"TVC_GEMM_SPLITK_TAIL": "1"}])
+@pytest.mark.parametrize("env", [{"TVC_GEMM_VARIANT": "2"}, {"TVC_GEMM_SPLITK_TAIL": "1"}, {"TVC_GEMM_SPLITK_SMALL": "1"}])
 def test_gemm_variants_in_subprocess(env):
     """Env switches read once per process: TVC_GEMM_VARIANT=2 selects gemm_solo_kernel for the
     ring-eligible bf16 GEMMs (incl. a ragged token remainder), TVC_GEMM_SPLITK_TAIL=1 the split-K tail
-    for left-over tile columns.  Same outputs as the PyTorch restatement."""
+    for left-over tile columns, TVC_GEMM_SPLITK_SMALL=1 split-K for GEMMs of a few tiles (latency mode).
+    Same outputs as the PyTorch restatement."""
     import os
     import subprocess
     import sys
@@ -163,7 +164,8 @@ import torch, tvc_amd as pkg
 eng = pkg.TVCEngine()
 g = torch.Generator(device="cuda:0").manual_seed(11)
 for I, J, K, epi in ((1024, 2048, 1024, 1), (768, 3000, 640, 2), (3072, 12800, 768, 2), (256, 2304, 4096, 1),
-                     (1024, 131584, 256, 1), (1024, 66000, 512, 2)):
+                     (1024, 131584, 256, 1), (1024, 66000, 512, 2), (1024, 257, 4096, 1), (3072, 300, 1024, 2),
+                     (768, 77, 768, 1)):
     a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
     bias = torch.randn(I, device="cuda:0", generator=g) * 3.0

@@ -224,74 +224,79 @@ hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const
 // text lengths: len[n] = argmax_t tok[n, t] + 1 (tokens up to and including EOT;
 // later positions cannot influence the pooled output under the causal mask);
 // starts = exclusive scan, starts[n_text] = total rows, starts[n_text+1] = max len.
-// One workgroup; n_text is a few thousand.
+// n_text is a few thousand.
 // ---------------------------------------------------------------------------
 // Prefix sharing (pfx != nullptr, texts in consecutive groups of G, first of a group = base text): a
 // causal tower gives two texts identical hidden states on their common prefix, so text n keeps only
 // the rows from its first token that differs from the base text on: starts[] then scans the OWN row
 // counts, pfx[n] = shared prefix length, pfx[n_text + n] = packed row of the base text's position 0.
-__global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __restrict__ tok,
-                                                               int32_t* __restrict__ starts,
-                                                               int32_t* __restrict__ pfx, int n_text, int ctx, int G) {
+//
+// Two kernels: `text_lens_kernel` (one wave per text, coalesced token reads, any number of
+// workgroups) parks own[n] in starts[n] and len[n] in lens[n] (= pfx[n_text + n] when sharing);
+// `text_scan_kernel` (one workgroup) turns them into the exclusive scan, the maximum length and the
+// base rows.  (One workgroup doing both spent 0.8 ms per step waiting on its own token reads.)
+__global__ __launch_bounds__(256) void text_lens_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ starts,
+                                                        int32_t* __restrict__ pfx, int32_t* __restrict__ lens,
+                                                        int n_text, int ctx, int G) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_text) return;
+    // len = position of the first maximum id + 1
+    int best = -1, best_t = 0;
+    for (int tt = lane; tt < ctx; tt += 64) {
+        const int v = tok[(int64_t)n * ctx + tt];
+        if (v > best) { best = v; best_t = tt; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ov = __shfl_xor(best, o, 64);
+        const int ot = __shfl_xor(best_t, o, 64);
+        if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
+    }
+    int len = best_t + 1, p = 0;
+    if (pfx) {
+        const int bn = n / G * G;
+        if (bn != n) {
+            // length of the base text, then the first position where the two differ
+            int bb = -1, bt = 0, mis = 0x7fffffff;
+            for (int tt = lane; tt < ctx; tt += 64) {
+                const int vb = tok[(int64_t)bn * ctx + tt], vn = tok[(int64_t)n * ctx + tt];
+                if (vb > bb) { bb = vb; bt = tt; }
+                if (vb != vn && tt < mis) mis = tt;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ov = __shfl_xor(bb, o, 64);
+                const int ot = __shfl_xor(bt, o, 64);
+                if (ov > bb || (ov == bb && ot < bt)) { bb = ov; bt = ot; }
+                const int om = __shfl_xor(mis, o, 64);
+                mis = om < mis ? om : mis;
+            }
+            p = mis;
+            if (p > len) p = len;
+            if (p > bt + 1) p = bt + 1;
+        }
+        if (lane == 0) pfx[n] = p;
+    }
+    if (lane == 0) { starts[n] = len - p; lens[n] = len; }
+}
+
+__global__ __launch_bounds__(1024) void text_scan_kernel(int32_t* __restrict__ starts, int32_t* __restrict__ pfx,
+                                                         const int32_t* __restrict__ lens, int n_text, int G) {
     __shared__ int part[1024];
     __shared__ int carry_s;
     __shared__ int maxlen_s;
     const int t = threadIdx.x;
     if (t == 0) { carry_s = 0; maxlen_s = 0; }
     __syncthreads();
-    // phase A: one wave per text, coalesced token reads; len = position of the first maximum id + 1
-    // (parked in starts[n], which phase B overwrites in place)
-    {
-        const int lane = t & 63, wave = t >> 6;
-        for (int n = wave; n < n_text; n += 16) {
-            int best = -1, best_t = 0;
-            for (int tt = lane; tt < ctx; tt += 64) {
-                const int v = tok[(int64_t)n * ctx + tt];
-                if (v > best) { best = v; best_t = tt; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ov = __shfl_xor(best, o, 64);
-                const int ot = __shfl_xor(best_t, o, 64);
-                if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
-            }
-            int len = best_t + 1, p = 0;
-            if (pfx) {
-                const int bn = n / G * G;
-                if (bn != n) {
-                    // length of the base text, then the first position where the two differ
-                    int bb = -1, bt = 0, mis = 0x7fffffff;
-                    for (int tt = lane; tt < ctx; tt += 64) {
-                        const int vb = tok[(int64_t)bn * ctx + tt], vn = tok[(int64_t)n * ctx + tt];
-                        if (vb > bb) { bb = vb; bt = tt; }
-                        if (vb != vn && tt < mis) mis = tt;
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const int ov = __shfl_xor(bb, o, 64);
-                        const int ot = __shfl_xor(bt, o, 64);
-                        if (ov > bb || (ov == bb && ot < bt)) { bb = ov; bt = ot; }
-                        const int om = __shfl_xor(mis, o, 64);
-                        mis = om < mis ? om : mis;
-                    }
-                    p = mis;
-                    if (p > len) p = len;
-                    if (p > bt + 1) p = bt + 1;
-                }
-                if (lane == 0) { pfx[n] = p; pfx[n_text + n] = len; }      // [n_text + n]: len parked for phase B
-            }
-            if (lane == 0) starts[n] = len - p;
-        }
-    }
-    __syncthreads();
     for (int base = 0; base < n_text; base += 1024) {
         const int n = base + t;
-        int len = 0;
+        int own = 0;
         if (n < n_text) {
-            len = starts[n];
-            atomicMax(&maxlen_s, pfx ? pfx[n_text + n] : len);      // attention length = prefix + own rows
+            own = starts[n];
+            atomicMax(&maxlen_s, lens[n]);                      // attention length = prefix + own rows
         }
-        part[t] = len;
+        part[t] = own;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
             const int v = (t >= o) ? part[t - o] : 0;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
             __syncthreads();
         }
         const int carry = carry_s;
-        if (n < n_text) starts[n] = carry + part[t] - len;
+        if (n < n_text) starts[n] = carry + part[t] - own;
         __syncthreads();
         if (t == 1023) carry_s = carry + part[1023];
         __syncthreads();
@@ -312,10 +317,15 @@ __global__ __launch_bounds__(1024) void text_lens_scan_kernel(const int32_t* __r
     }
 }
 
+// lens_ws: int32 [n_text] scratch (ignored with pfx, whose second half is used)
 hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int32_t* pfx, int n_text, int ctx, int G,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int32_t* lens_ws) {
     if (pfx && G < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(text_lens_scan_kernel, dim3(1), dim3(1024), 0, stream, tok, starts, pfx, n_text, ctx, G);
+    int32_t* lens = pfx ? pfx + n_text : lens_ws;
+    if (!lens) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(text_lens_kernel, dim3((n_text + 3) / 4), dim3(256), 0, stream, tok, starts, pfx, lens, n_text,
+                       ctx, G);
+    hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(1024), 0, stream, starts, pfx, lens, n_text, G);
     return hipGetLastError();
 }
 

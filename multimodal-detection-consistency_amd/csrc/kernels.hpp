@@ -46,7 +46,7 @@ hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const flo
 // starts[n_text + 1] = max length; pfx (optional, int32 [2 * n_text], groups of G texts): [n] = shared
 // prefix length, [n_text + n] = packed row of the base text's position 0
 hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int32_t* pfx, int n_text, int ctx, int G,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int32_t* lens_ws);
 hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream);
 hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
                                hipStream_t stream);

@@ -20,7 +20,7 @@ enum Slot {
     // concurrently on two streams
     WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_TOWER_N,
     WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK,
-    WS_PATCH, WS_EOT, WS_STARTS, WS_PFX,
+    WS_PATCH, WS_EOT, WS_STARTS, WS_PFX, WS_LENS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
     WS_COUNT
@@ -333,6 +333,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     if (share && (rc = ensure(h, WS_PFX, (size_t)chunk * 2 * 4))) return rc;
     if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
     if ((rc = ensure(h, WS_STARTS, (size_t)(chunk + 2) * 4))) return rc;
+    if ((rc = ensure(h, WS_LENS, (size_t)chunk * 4))) return rc;
     for (int t0 = 0; t0 < Tn; t0 += chunk) {
         const int n = (Tn - t0 < chunk) ? Tn - t0 : chunk;
         int32_t* eot = (int32_t*)h->ws[WS_EOT].p;
@@ -346,7 +347,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
             // The row count sizes the GEMM grids, hence ONE 8-byte read-back per call.
             int32_t* sd = (int32_t*)h->ws[WS_STARTS].p;
             int32_t* pd = share ? (int32_t*)h->ws[WS_PFX].p : nullptr;
-            HIP_TRY(launch_text_lens_scan(tok, sd, pd, n, ctx, G, st));
+            HIP_TRY(launch_text_lens_scan(tok, sd, pd, n, ctx, G, st, (int32_t*)h->ws[WS_LENS].p));
             pfx = pd;
             int32_t tail[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(tail, sd + n, sizeof tail, hipMemcpyDeviceToHost, st));

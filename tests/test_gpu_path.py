@@ -281,6 +281,12 @@ def test_text_prefix_sharing_is_bit_identical(pkg, model, ctx_lens):
     assert torch.equal(shared, plain)
     # a batch that is not a whole number of groups silently falls back to the plain packed path
     assert torch.equal(eng.encode_text(flat[:-1]).cpu(), plain[:-1])
+    # several passes: the chunk is cut to whole groups (here 2 groups per pass), or sharing is dropped
+    # when a pass cannot hold one group
+    eng.set_option(pkg._lib.TVC_OPT_MAX_CHUNK_TEXTS, 2 * (N + 1) + 1)
+    assert torch.equal(eng.encode_text(flat).cpu(), plain)
+    eng.set_option(pkg._lib.TVC_OPT_MAX_CHUNK_TEXTS, N)
+    assert torch.equal(eng.encode_text(flat).cpu(), plain)
     eng.close()
 
 

@@ -15,8 +15,10 @@ Two independent axes:
      b. every rank searches ALL ``W*m`` rows against its shard (exact local
         top-k with global indices) and gathers the ``kf`` best rows' features;
      c. all-to-all: rank r receives, for ITS OWN m rows, the W partial lists
-        (``m x k x 8 B`` + ``m x kf x D x 4 B`` per peer: ~10 MB per pair) --
-        xGMI is point-to-point, every link carries a distinct peer's slice;
+        (``m x k x 8 B`` + ``m x kf x D x 4 B`` per peer: 0.2 MB + 78.6 MB per pair at
+        m = 5120, kf = 5, D = 768) -- xGMI is point-to-point, every link carries a
+        distinct peer's slice.  (A two-phase exchange - indices + similarities, merge,
+        then only the winners' rows - would cut the row traffic W-fold)
      d. ``tvc_topk_merge`` merges the W sorted partials (HIP kernel).
    The ``[M, R]`` similarity rows are never exchanged.
 

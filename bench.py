@@ -127,7 +127,8 @@ def main():
     if a.shard_bank:
         lo, hi = pkg.sharding.shard_bounds(R, world, rank)
         bank = pkg.synth.make_bank(hi - lo, D, seed=7 + rank, device=str(dev), dtype=torch.bfloat16)
-        sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3))
+        sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3),
+                                                 rows_per_shard=(R + world - 1) // world)
     else:
         bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
     eng.set_bank(bank)

@@ -17,9 +17,10 @@ Two independent axes:
      c. all-to-all: rank r receives, for ITS OWN m rows, the W partial lists
         (``m x k x 8 B`` + ``m x kf x D x 4 B`` per peer: 0.2 MB + 78.6 MB per pair at
         m = 5120, kf = 5, D = 768) -- xGMI is point-to-point, every link carries a
-        distinct peer's slice.  (A two-phase exchange - indices + similarities, merge,
-        then only the winners' rows - would cut the row traffic W-fold)
+        distinct peer's slice;
      d. ``tvc_topk_merge`` merges the W sorted partials (HIP kernel).
+   With ``rows_per_shard`` given, (c) carries indices + similarities only and two small
+   variable-size all-to-alls (e, f) fetch just the winners' rows from their owners.
    The ``[M, R]`` similarity rows are never exchanged.
 
 The collectives move small tensors; all arithmetic stays in the HIP kernels.
@@ -49,7 +50,7 @@ def split_queries(n: int, world: int, rank: int) -> Tuple[int, int]:
 class ShardOps(Protocol):
     def search(self, rows: torch.Tensor, k: int): ...            # -> idx [M,k] (global), sim [M,k]
     def gather(self, idx: torch.Tensor): ...                      # global idx [M,kf] -> feat [M,kf,D]
-    def merge(self, idx_parts, sim_parts, feat_parts): ...        # [W,M,*] -> idx, sim, feat
+    def merge(self, idx_parts, sim_parts, feat_parts): ...        # [W,M,*] -> idx, sim, feat (feat_parts may be None)
 
 
 class HipShardOps:
@@ -86,14 +87,42 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group) -> None:
         out[w].copy_(bufs[w][me])
 
 
-class ShardedBankSearch:
-    """Exact global top-k over a row-sharded bank for data-parallel query rows."""
+def _exchange_lists(send, group):
+    """send[w] = 1-D/2-D tensor for rank w (any lengths) -> recv[w] = what rank w sent to me.
+    RCCL: counts by all_to_all_single, then ONE all_to_all_single with split sizes; gloo (CPU
+    tests): all_gather_object."""
+    W = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    if dist.get_backend(group) != "nccl":
+        box = [None] * W
+        dist.all_gather_object(box, [t.cpu() for t in send], group=group)
+        return [box[w][me].to(send[0].device) for w in range(W)]
+    dev = send[0].device
+    cnt_out = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=dev)
+    cnt_in = torch.empty_like(cnt_out)
+    dist.all_to_all_single(cnt_in, cnt_out, group=group)
+    n_in = cnt_in.tolist()
+    tail = tuple(send[0].shape[1:])
+    out = torch.empty((sum(n_in),) + tail, dtype=send[0].dtype, device=dev)
+    dist.all_to_all_single(out, torch.cat(send).contiguous(), output_split_sizes=n_in,
+                           input_split_sizes=cnt_out.tolist(), group=group)
+    return list(out.split(n_in))
 
-    def __init__(self, ops: ShardOps, group=None):
+
+class ShardedBankSearch:
+    """Exact global top-k over a row-sharded bank for data-parallel query rows.
+
+    ``rows_per_shard`` (= ``ceil(R / W)``, the split of ``shard_bounds``) enables the two-phase
+    exchange: indices + similarities first, merge, then ONLY the winners' rows travel (each from the
+    shard that owns it): ``m x kf x D x 4 B`` per rank instead of W times that.  Without it the
+    single-phase form (every shard ships the rows of its own kf best) is used."""
+
+    def __init__(self, ops: ShardOps, group=None, rows_per_shard: Optional[int] = None):
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.rows_per_shard = rows_per_shard
 
     def search(self, rows: torch.Tensor, k: int, kf: int):
         """rows [m, D] (this rank's query-side rows; m equal on every rank) ->
@@ -102,14 +131,29 @@ class ShardedBankSearch:
         allrows = torch.empty((W * m, D), dtype=rows.dtype, device=rows.device)
         dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)         # (a)
         idx, sim = self.ops.search(allrows, k)                                            # (b)
-        feat = self.ops.gather(idx[:, :kf])
         idx_in = torch.empty((W, m, k), dtype=idx.dtype, device=rows.device)
         sim_in = torch.empty((W, m, k), dtype=sim.dtype, device=rows.device)
-        feat_in = torch.empty((W, m, kf, D), dtype=feat.dtype, device=rows.device)
         _all_to_all(idx_in, idx.view(W, m, k), self.group)                                 # (c)
         _all_to_all(sim_in, sim.view(W, m, k), self.group)
-        _all_to_all(feat_in, feat.view(W, m, kf, D), self.group)
-        return self.ops.merge(idx_in, sim_in, feat_in)                                    # (d)
+        if self.rows_per_shard is None:
+            feat = self.ops.gather(idx[:, :kf])
+            feat_in = torch.empty((W, m, kf, D), dtype=feat.dtype, device=rows.device)
+            _all_to_all(feat_in, feat.view(W, m, kf, D), self.group)
+            return self.ops.merge(idx_in, sim_in, feat_in)                                # (d)
+        # ---- two-phase: merge the lists, then fetch the winners' rows from their owners
+        midx, msim, _ = self.ops.merge(idx_in, sim_in, None)                              # (d)
+        win = midx[:, :kf].reshape(-1)                                                    # [m*kf] global, -1 = none
+        owner = torch.where(win >= 0, torch.clamp(win // self.rows_per_shard, max=W - 1), torch.full_like(win, -1))
+        pos = [torch.nonzero(owner == w).flatten() for w in range(W)]
+        asked = _exchange_lists([win[p_] for p_ in pos], self.group)                      # (e) who wants which of my rows
+        sent = [self.ops.gather(a.view(-1, 1)).view(-1, D) if a.numel() else
+                torch.empty((0, D), dtype=torch.float32, device=rows.device) for a in asked]
+        got = _exchange_lists(sent, self.group)                                           # (f) the rows come back
+        feat = torch.zeros((m * kf, D), dtype=torch.float32, device=rows.device)
+        for w in range(W):
+            if pos[w].numel():
+                feat[pos[w]] = got[w].to(feat.dtype)
+        return midx, msim, feat.view(m, kf, D)
 
 
 def detect_sharded(engine, search: ShardedBankSearch, img: torch.Tensor, txt: torch.Tensor, cfg) -> torch.Tensor:

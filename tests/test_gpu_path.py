@@ -318,3 +318,25 @@ def test_two_shard_search_equals_full_search(gpu_engine):
         assert torch.equal(mi, fi) and torch.equal(ms, fs) and torch.equal(mf, ff)
         if want_moments:
             assert (mm[:, 3].cpu() - (S >= 0.05).sum(1).cpu()).abs().max() <= 1
+
+
+def test_sharded_search_two_phase_on_gpu(gpu_engine, pkg, tmp_path):
+    """``ShardedBankSearch`` with the product ops (``HipShardOps``) in a one-rank process group: the
+    two-phase exchange (merge of index / similarity lists, then only the winners' rows) returns what a
+    direct search + gather returns, bit for bit; so does the single-phase form."""
+    import torch.distributed as dist
+    R, D, M, k, kf = 30011, 256, 130, 8, 5
+    bank = _unit((R, D), 41).to(torch.bfloat16).cuda()
+    q = _unit((M, D), 42).cuda()
+    gpu_engine.set_bank(bank)
+    ri, rs, _ = gpu_engine.bank_search(q, k, 0.3, want_moments=False)
+    rf = gpu_engine.bank_gather(ri[:, :kf].contiguous())
+    gpu_engine.bank_status()
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        for per in (None, R):
+            s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=per)
+            i, v, f = s.search(q, k, kf)
+            assert torch.equal(i, ri) and torch.equal(v, rs) and torch.equal(f, rf)
+    finally:
+        dist.destroy_process_group()

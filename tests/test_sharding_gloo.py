@@ -40,6 +40,13 @@ class NumpyShardOps:
 
     def merge(self, idx_parts, sim_parts, feat_parts):
         W, M, k = idx_parts.shape
+        if feat_parts is None:
+            idx = idx_parts.permute(1, 0, 2).reshape(M, W * k).numpy()
+            sim = sim_parts.permute(1, 0, 2).reshape(M, W * k).numpy().astype(np.float64)
+            sim = np.where(idx >= 0, sim, -np.inf)
+            order = np.lexsort((idx, -sim), axis=1)[:, :k]
+            return (torch.from_numpy(np.take_along_axis(idx, order, 1)),
+                    torch.from_numpy(np.take_along_axis(sim, order, 1).astype(np.float32)), None)
         kf = feat_parts.shape[2]
         idx = idx_parts.permute(1, 0, 2).reshape(M, W * k).numpy()
         sim = sim_parts.permute(1, 0, 2).reshape(M, W * k).numpy().astype(np.float64)
@@ -57,7 +64,7 @@ class NumpyShardOps:
         return torch.from_numpy(oi), torch.from_numpy(osim), torch.from_numpy(of)
 
 
-def _worker(rank, world, port, R, D, m, k, kf, out_dir):
+def _worker(rank, world, port, R, D, m, k, kf, out_dir, two_phase):
     sys.path.insert(0, str(ROOT))
     import importlib
     pkg = importlib.import_module("multimodal-detection-consistency_amd")
@@ -70,7 +77,8 @@ def _worker(rank, world, port, R, D, m, k, kf, out_dir):
     q_all = rng.standard_normal((world * m, D)).astype(np.float32)
     q_all /= np.linalg.norm(q_all, axis=1, keepdims=True)
     lo, hi = pkg.sharding.shard_bounds(R, world, rank)
-    search = pkg.sharding.ShardedBankSearch(NumpyShardOps(bank[lo:hi], lo))
+    per = (R + world - 1) // world
+    search = pkg.sharding.ShardedBankSearch(NumpyShardOps(bank[lo:hi], lo), rows_per_shard=per if two_phase else None)
     mine = torch.from_numpy(q_all[rank * m:(rank + 1) * m])
     idx, sim, feat = search.search(mine, k, kf)
     np.savez(Path(out_dir) / f"r{rank}.npz", idx=idx.numpy(), sim=sim.numpy(), feat=feat.numpy(), bank=bank, q=mine.numpy())
@@ -78,11 +86,12 @@ def _worker(rank, world, port, R, D, m, k, kf, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("two_phase", [False, True])
 @pytest.mark.parametrize("R", [1001, 7])
-def test_sharded_search_matches_global(tmp_path, R):
+def test_sharded_search_matches_global(tmp_path, R, two_phase):
     world, D, m, k, kf = 2, 32, 6, 5, 3
-    port = 29500 + (os.getpid() % 2000) + R % 7
-    mp.spawn(_worker, args=(world, port, R, D, m, k, kf, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + R % 7 + 11 * int(two_phase)
+    mp.spawn(_worker, args=(world, port, R, D, m, k, kf, str(tmp_path), two_phase), nprocs=world, join=True)
     for rank in range(world):
         g = np.load(tmp_path / f"r{rank}.npz")
         S = g["q"].astype(np.float64) @ g["bank"].astype(np.float64).T

@@ -7,17 +7,25 @@ towers, exact top-k search of all B*(N+2) embedding rows against the bank,
 per-query consistency scores, records copied to the host.  Default workload =
 BASELINE.json configs[2]: ViT-L/14 bf16, B=512, N=8, 1M-row bank, one GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: queries are data-parallel (encoders replicated, bank replicated per
-GPU, no collective on the data path) -> "scaling": "weak".  Rank 0 prints ONE
-JSON line.
+Multi-GPU (one process per GPU, torch.distributed backend nccl = RCCL over xGMI):
+  * default: queries are data-parallel (encoders + bank replicated per GPU, no
+    collective on the data path) -> "scaling": "weak";
+  * --shard-bank (BASELINE configs[3]): --bank-rows is the GLOBAL bank, row-sharded
+    over the ranks; all-gather of the query rows + all-to-all of partial top-k lists.
+Rank 0 prints ONE JSON line.  With --gpus N > 1 and no WORLD_SIZE in the environment
+this process never touches the GPU: it starts `python -m torch.distributed.run` with N
+fresh worker processes, forwards their output and exits with their code (replaces
+src/utils/multi_gpu_processor.py:494-620 at the driver's entry point).
 """
 import argparse
 import importlib
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -28,7 +36,7 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
@@ -36,9 +44,13 @@ def parse():
     p.add_argument("--model", default="ViT-L/14")
     p.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
     p.add_argument("--variants", type=int, default=8)
-    p.add_argument("--bank-rows", type=int, default=1_000_000)
+    p.add_argument("--bank-rows", type=int, default=None,
+                   help="bank rows (default 1 000 000 = configs[2]; 10 000 000 with --shard-bank = configs[3])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the extra measurements of the default N=1 run (dense-text rate, through-the-API rates, "
+                        "reference-schedule / 1-thread / configs[0] CPU baselines)")
     p.add_argument("--no-profile-pass", action="store_true")
     p.add_argument("--shard-bank", action="store_true",
                    help="BASELINE configs[3]: --bank-rows is the GLOBAL bank, row-sharded over the ranks; "
@@ -54,7 +66,55 @@ def parse():
                         "in common with their original - bit-identical, see TVC_OPT_TEXT_GROUP)")
     p.add_argument("--dense-text", action="store_true",
                    help="run the text tower on all 77 positions (disable EOT packing)")
-    return p.parse_args()
+    p.add_argument("--unplanted-bank", action="store_true",
+                   help="pure Gaussian bank (no row reaches the 0.3 threshold, the reference branch of the consistency "
+                        "kernel sees no references); default: neighbours of the text rows are planted")
+    p.add_argument("--master-port", type=int, default=0)
+    p.add_argument("--dry-run-launch", action="store_true",
+                   help="launch-contract rehearsal WITHOUT a GPU (CPU test of the --gpus N launcher): the ranks form a "
+                        "gloo group, run the barrier + max-over-ranks reduction and rank 0 prints a line with "
+                        '"dry_run": true and value 0 -- never a measurement')
+    a = p.parse_args(argv)
+    if a.bank_rows is None:
+        a.bank_rows = 10_000_000 if a.shard_bank else 1_000_000
+    return a
+
+
+# --------------------------------------------------------------------------- launcher
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N worker ranks (fresh processes; this
+    parent has not initialised the GPU), stream their output, return their exit code."""
+    import torch
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU on this image
+    if not a.rehearse_one_gpu and not a.dry_run_launch and have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 3
+    port = a.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is None:
+        print(f"bench.py: the {a.gpus}-rank run produced no result line (exit code {rc})", file=sys.stderr)
+        return rc or 4
+    try:
+        n = json.loads(line).get("n_gpus")
+    except Exception:
+        n = None
+    if n != a.gpus:
+        print(f"bench.py: asked for {a.gpus} ranks, the result line says n_gpus={n}", file=sys.stderr)
+        return rc or 5
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    return rc
 
 
 def host_cpus() -> int:
@@ -69,26 +129,38 @@ def host_cpus() -> int:
     return n
 
 
-def cpu_baseline(pkg, arch, weights, images, tokens, bank_cpu, budget_s):
-    """The oracle (CPU restatement of the reference path, PyTorch-CPU fp32 towers +
-    numpy scores) timed on this box's host cores on a bounded sample of the same
-    workload, de-duplicated schedule (image encoded once per query)."""
-    import numpy as np
+# --------------------------------------------------------------------------- CPU baselines (oracle = checker / timed port)
+def cpu_baseline(arch, weights, images, tokens, bank_cpu, budget_s, threads, schedule="dedup", max_queries=None):
+    """The oracle (CPU restatement of the reference path, PyTorch-CPU fp32 towers + numpy scores) timed on
+    this box's host cores on a bounded sample of the same workload.
+    schedule "dedup": image encoded once per query, the N+1 texts in one batch (the de-duplicated minimum);
+    schedule "reference": the reference's own schedule, src/detector.py:461-471 + :573 -- one image forward and
+    one text forward per get_text_image_similarity call (N+1 for the variants method, one more for the
+    consistency method), i.e. N+2 image-tower passes per query."""
     import torch
     from oracle import clip_oracle, tvc_oracle
     vw, tw = weights
-    torch.set_num_threads(host_cpus())      # more threads than the cgroup quota only thrash
+    torch.set_num_threads(threads)
 
     def one(i):
         with torch.no_grad():
-            fi = clip_oracle.vision_forward(vw, images[i:i + 1], arch.vision.heads, arch.patch)
-            ft = clip_oracle.text_forward(tw, tokens[i], arch.text.heads)
+            if schedule == "dedup":
+                fi = clip_oracle.vision_forward(vw, images[i:i + 1], arch.vision.heads, arch.patch)
+                ft = clip_oracle.text_forward(tw, tokens[i], arch.text.heads)
+            else:
+                fis, fts = [], []
+                for n in list(range(tokens.shape[1])) + [0]:          # N+1 similarity calls + the consistency call
+                    fis.append(clip_oracle.vision_forward(vw, images[i:i + 1], arch.vision.heads, arch.patch))
+                    fts.append(clip_oracle.text_forward(tw, tokens[i, n:n + 1], arch.text.heads))
+                fi, ft = fis[0], torch.cat(fts[:-1])
         return tvc_oracle.detect_batch(fi.numpy(), ft.numpy()[None], bank_cpu)
 
-    one(0)                      # warm-up (thread pools, allocator)
+    if schedule == "dedup" and threads > 1:
+        one(0)                  # warm-up (thread pools, allocator)
     t0 = time.perf_counter()
     done = 0
-    while done < images.shape[0]:
+    limit = images.shape[0] if max_queries is None else min(max_queries, images.shape[0])
+    while done < limit:
         one(done)
         done += 1
         if time.perf_counter() - t0 > budget_s:
@@ -97,15 +169,61 @@ def cpu_baseline(pkg, arch, weights, images, tokens, bank_cpu, budget_s):
     return done / dt, done, dt
 
 
+# --------------------------------------------------------------------------- synthetic strings for the API-level runs
+class WordReplaceVariants:
+    """Variant generator for the through-the-API measurement: replaces ceil(0.3 * words) words of the
+    caption in place (``synonym_replacement_ratio`` 0.3, src/text_augment.py:57) -- the string-level
+    twin of ``synth.make_tokens``, so both measurements see the same token statistics."""
+
+    def __init__(self, n, vocab, seed=5):
+        import random
+        self.n, self.vocab, self.rng = n, vocab, random.Random(seed)
+
+    def generate_variants(self, text):
+        words = text.split()
+        out = []
+        for _ in range(self.n):
+            w = list(words)
+            for p in self.rng.sample(range(len(w)), int(math.ceil(0.3 * len(w)))):
+                w[p] = self.rng.choice(self.vocab)
+            out.append(" ".join(w))
+        return out
+
+
+def make_captions(n, seed=3):
+    import random
+    rng = random.Random(seed)
+    vocab = [f"w{i}" for i in range(4000)]
+    return [" ".join(rng.choice(vocab) for _ in range(rng.randint(5, 20))) for _ in range(n)], vocab
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+
     import torch
     import torch.distributed as dist
-    pkg = importlib.import_module("multimodal-detection-consistency_amd")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_run_launch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.tensor([1e-3 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "defended queries/sec", "value": 0.0, "unit": "queries/s", "n_gpus": world,
+                              "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+                              "max_over_ranks_s": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    pkg = importlib.import_module("multimodal-detection-consistency_amd")
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     if a.rehearse_one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -121,16 +239,24 @@ def main():
     arch = pkg.get_arch(a.model)
     B, N, R, D = a.batch, a.variants, a.bank_rows, arch.embed_dim
     weights = pkg.synth.make_clip_weights(arch, seed=0)
-    eng = pkg.TVCEngine(arch, weights[0], weights[1], device=str(dev))
+    clip = pkg.CLIPModel(pkg.CLIPConfig(model_name=a.model, device=str(dev)), weights=weights)
+    eng = clip.engine
     images = pkg.synth.make_images(B, arch.image_size, seed=1 + rank).to(dev)
     tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2 + 1000 * rank).to(dev)
     if a.shard_bank:
         lo, hi = pkg.sharding.shard_bounds(R, world, rank)
         bank = pkg.synth.make_bank(hi - lo, D, seed=7 + rank, device=str(dev), dtype=torch.bfloat16)
-        sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3),
-                                                 rows_per_shard=(R + world - 1) // world)
     else:
         bank = pkg.synth.make_bank(R, D, seed=7, device=str(dev), dtype=torch.bfloat16)
+    if not a.unplanted_bank and bank.shape[0] >= 4 * B * (N + 1):
+        # neighbours of this rank's text rows (cos 0.45 .. 0.99): retrieval keeps references above the 0.3
+        # threshold, so the de-duplication / cos(image, reference) branch of the consistency kernel runs
+        ft0 = eng.encode_text(tokens.view(B * (N + 1), arch.ctx))
+        bank = pkg.synth.plant_neighbours(bank, ft0.cpu(), per_anchor=1, seed=11 + rank)
+        del ft0
+    if a.shard_bank:
+        sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3),
+                                                 rows_per_shard=(R + world - 1) // world)
     eng.set_bank(bank)
     if a.dense_text:
         eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
@@ -174,21 +300,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    eng.bank_status()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rec, _ = step()
-    sync()
-    dt = time.perf_counter() - t0
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            out = fn()
+        if not a.shard_bank:
+            eng.bank_status()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        sync()
+        return time.perf_counter() - t0, out
+
+    dt, (rec, _) = timed(step, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([dt], device="cpu" if a.rehearse_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    eng.bank_status()
+    if not a.shard_bank:
+        eng.bank_status()                     # (the sharded search is status-checked per call)
     assert torch.isfinite(rec[:, :11]).all()      # words >= 12+N hold int32 bit patterns (-1 = NaN bits)
+    kept_refs = float(rec[:, 8].mean())           # references kept per query by the consistency kernel
 
     roof = None
     prof = None
@@ -205,24 +337,24 @@ def main():
                 "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
 
     if roof is not None and rank == 0:
-        # HBM bytes per launch of the dominant kernel family from the committed PMC summary of this
-        # command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bench.py cannot collect counters)
+        # HBM bytes per launch of the dominant kernel family: NOT measured by this run (bench.py cannot collect
+        # PMC counters); a static figure from the committed rocprofv3 --pmc summary of this same command
         try:
             import glob
-            import json as _json
             here = os.path.dirname(os.path.abspath(__file__))
             files = sorted(glob.glob(os.path.join(here, "profiles", "*hbm_traffic_pmc.json")))
-            if files and a.model == "ViT-L/14" and B == 512 and N == 8 and R == 1_000_000:
-                pm = _json.load(open(files[-1]))
-                ring = [(v["launches"], v["hbm_MB_per_launch_corrected"]) for k, v in pm.items()
-                        if k.startswith("gemm_ring_kernel")]
+            if files and a.model == "ViT-L/14" and B == 512 and N == 8 and R == 1_000_000 and not a.shard_bank:
+                pm = json.load(open(files[-1]))
+                ring = [(v["launches"], v["hbm_MB_per_launch_corrected"]) for kk, v in pm.items()
+                        if kk.startswith("gemm_ring_kernel")]
                 if ring:
                     roof["traffic"] = round(sum(n * mb for n, mb in ring) / sum(n for n, _ in ring) / 1e3, 3)
                     roof["traffic_unit"] = "GB per launch (PMC, launch-weighted mean over the ring GEMMs)"
-                    roof["traffic_source"] = "profiles/" + os.path.basename(files[-1])
+                    roof["traffic_source"] = "static (from committed profile): profiles/" + os.path.basename(files[-1])
         except Exception:       # a missing / unreadable summary leaves traffic null
             pass
 
+    out = None
     if rank == 0:
         qps = world * B * a.steps / dt
         flops_q = arch.flops_image() + (N + 1) * arch.flops_text() + 2.0 * (N + 2) * R * D
@@ -231,16 +363,26 @@ def main():
         exec_flops = None
         if prof:
             exec_flops = prof["gemm"]["work"] + prof["attention"]["work"] + prof["bank"]["work"]
+        if a.shard_bank:
+            wl = (f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank row-sharded over {world} GPU(s) "
+                  f"({-(-R // world)} rows each), encode + exact top-{k} search with RCCL all-gather / all-to-all of partial "
+                  f"lists + consistency (BASELINE configs[3])")
+        else:
+            tag = "BASELINE configs[2]" if (a.model, B, N, R) == ("ViT-L/14", 512, 8, 1_000_000) else \
+                  "BASELINE configs[1]" if (a.model, B, N, R) == ("ViT-B/32", 256, 4, 100_000) else "custom"
+            wl = (f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank, "
+                  f"encode + exact top-{k} bank search + consistency ({tag})")
         out = {
             "metric": "defended queries/sec", "value": round(qps, 2), "unit": "queries/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{a.model} bf16, batch={B}/GPU, N={N} variants, {R}-row bf16 bank, "
-                                   f"encode + exact top-{k} bank search + consistency (BASELINE configs[2])",
+            "config": {"workload": wl,
                        "global_batch": world * B, "parallelism": (f"dp{world} queries x bank rows sharded {world}-way (RCCL all-gather + all-to-all of partial top-k)"
                                        if a.shard_bank else f"dp{world}"),
                        "text_packing": "dense-77" if a.dense_text else ("eot-packed" + ("" if a.no_prefix_sharing else " + variant prefix sharing") + " (bit-identical, see DESIGN.md)"),
+                       "bank": "gaussian" if a.unplanted_bank else "gaussian + planted neighbours of the text rows",
+                       "references_kept_per_query": round(kept_refs, 2),
                        "algorithmic_gflop_per_query_dense": round(flops_q / 1e9, 2),
                        "executed_gflop_per_query": round(exec_flops / B / 1e9, 2) if exec_flops else None,
                        "executed_path_tflops": round(qps * exec_flops / B / 1e12, 1) if exec_flops else None},
@@ -251,18 +393,72 @@ def main():
             bk = prof["bank"]
             if bk["ms"] > 0:
                 out["bank_stage"] = {"mfma_tflops": round(bk["work"] / (bk["ms"] * 1e-3) / 1e12, 1),
-                                     "bank_stream_GBps": round(R * D * 2 / (bk["ms"] * 1e-3) / 1e9, 1)}
-        if not a.no_cpu_baseline and world == 1:
-            import numpy as np
-            nq = min(B, 64)
-            bank_cpu = bank.float().cpu().numpy()
-            v, done, secs = cpu_baseline(pkg, arch, weights, images[:nq].cpu(), tokens[:nq].cpu().long(), bank_cpu,
-                                         a.cpu_seconds)
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
-                                   "sample": f"{done} queries of the same workload in {secs:.1f}s, oracle "
-                                             f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}
-            out["speedup_vs_cpu"] = round(qps / v, 1) if v > 0 else None
+                                     "bank_stream_GBps": round(bank.shape[0] * D * 2 / (bk["ms"] * 1e-3) / 1e9, 1)}
+
+    extras = world == 1 and not a.no_extras and not a.shard_bank
+    if extras and not a.dense_text:
+        # the same workload with the text tower on all 77 positions (no EOT packing): the rate does not
+        # depend on caption length
+        eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
+        d2, _ = timed(step, max(2, min(a.steps, 5)), 1)
+        eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 1)
+        out["dense_text_qps"] = round(B * max(2, min(a.steps, 5)) / d2, 2)
+    if extras:
+        # ---- the same workload through the API the reference's runners call: strings + image tensors in,
+        # Python result objects out (experiments/runners/run_detection.py:164-203, run_ablation.py:308-312)
+        texts, vocab = make_captions(B)
+        gen = WordReplaceVariants(N, vocab)
+        pipe = pkg.MultiModalDetectionPipeline(
+            pkg.PipelineConfig(enable_sd_reference=False,
+                               detector_config=pkg.DetectorConfig(clip_model=a.model, num_text_variants=N)),
+            clip_model=clip, text_augmenter=gen)
+        pipe.retriever.set_image_features(bank)                     # the retriever's own bank slot (same rows)
+        defense = pkg.MultiModalDefenseDetector(clip, config=pkg.DetectionConfig(text_variant_count=N),
+                                                text_generator=gen)
+        defense.set_reference_bank(bank)
+        ks = max(2, min(a.steps, 5))
+        d_pipe, res = timed(lambda: pipe.detect(images=images, texts=texts, return_details=True), ks, 1)
+        assert len(res["scores"]) == B
+        d_def, res = timed(lambda: defense.batch_detect(images, texts), ks, 1)
+        assert len(res) == B
+        out["through_api"] = {
+            "pipeline_detect_qps": round(B * ks / d_pipe, 2), "defense_batch_detect_qps": round(B * ks / d_def, 2),
+            "engine_level_qps": out["value"],
+            "note": "strings + device image tensors in, Python result objects out; pipeline.detect = text_augment + "
+                    "retrieval (B texts re-encoded + top-5 of the 1M-row index) + detection (src polarity, no bank); "
+                    "defense.batch_detect = encode + bank search of the B*(N+1) text rows + consistency + the stateful "
+                    "host-side ConsistencyChecker"}
+
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        nq = min(B, 64)
+        cores = host_cpus()             # more threads than the cgroup quota only thrash
+        bank_cpu = bank.float().cpu().numpy()
+        img_c, tok_c = images[:nq].cpu(), tokens[:nq].cpu().long()
+        v, done, secs = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, a.cpu_seconds, cores)
+        out["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{done} queries of the same workload in {secs:.1f}s, oracle "
+                                         f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}
+        out["speedup_vs_cpu"] = round(out["value"] / v, 1) if v > 0 else None
+        if extras:
+            more = {}
+            v2, d2, s2 = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, 12.0, cores, schedule="reference", max_queries=4)
+            more["reference_schedule"] = {"value": round(v2, 4), "unit": "queries/s", "cores": cores, "kind": "port",
+                                          "sample": f"{d2} queries in {s2:.1f}s, the reference's schedule (src/detector.py:461-471,573: "
+                                                    f"N+2 image-tower passes and N+2 single-text passes per query)"}
+            v3, d3, s3 = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, 10.0, 1, max_queries=2)
+            more["one_thread"] = {"value": round(v3, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+                                  "sample": f"{d3} queries in {s3:.1f}s, de-duplicated schedule, torch.set_num_threads(1)"}
+            # BASELINE configs[0] exactly: ViT-B/32, batch 8, N = 4, 1k-row bank, on the CPU
+            a0 = pkg.get_arch("ViT-B/32")
+            w0 = pkg.synth.make_clip_weights(a0, seed=0)
+            i0 = pkg.synth.make_images(8, a0.image_size, seed=1)
+            t0 = pkg.synth.make_tokens(8, 4, a0.ctx, seed=2).long()
+            b0 = pkg.synth.make_bank(1000, a0.embed_dim, seed=7).numpy()
+            v4, d4, s4 = cpu_baseline(a0, w0, i0, t0, b0, 10.0, cores)
+            more["configs0_vit_b32_b8_n4_r1k"] = {"value": round(v4, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+                                                   "sample": f"{d4} queries in {s4:.1f}s, de-duplicated schedule (BASELINE configs[0])"}
+            out["cpu_baselines_extra"] = more
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or a.shard_bank:
         dist.destroy_process_group()

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define TVC_ABI_VERSION 1
+#define TVC_ABI_VERSION 2
+#define TVC_MAX_BANKS 8      /* bank slots per handle (tvc_bank_select)          */
+#define TVC_MAX_TOPK 128     /* largest k of tvc_bank_search / tvc_topk_merge    */
 
 enum {
     TVC_OK = 0,
@@ -159,6 +161,12 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t T,
 
 /* ---- reference bank (K5) --------------------------------------------- */
 
+/* A handle holds TVC_MAX_BANKS independent bank slots so that several owners sharing one engine (the
+ * retriever's image index src/retrieval.py:225, a ReferenceBank src/ref_bank.py:86, the defense detector's
+ * reference features retrieval_ref.py:99) cannot replace each other's rows.  tvc_bank_select picks the slot
+ * that tvc_bank_set / _search / _search_dense / _gather address from then on (default: slot 0). */
+int tvc_bank_select(tvc_handle* h, int32_t slot);
+
 /* Register the bank: dense row-major [R, D], rows L2-normalised
  * (scripts/build_faiss_indices.py:108-109,138; retrieval_ref.py:99,156).
  * dtype TVC_DTYPE_BF16: used in place (caller keeps it alive).
@@ -172,7 +180,7 @@ int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D,
 /* Exact top-k inner-product search of M query rows against the bank, fused
  * with per-row moments; the [M, R] matrix is never materialised.
  *   rows_dev   fp32 [M, D] (L2-normalised by the caller when cosines are wanted)
- *   k          1..32
+ *   k          1..TVC_MAX_TOPK (128)
  *   topk_idx   int32 [M, k]  global row index (local + idx_offset), -1 = none
  *   topk_sim   fp32  [M, k]  descending; ties broken by ascending index
  *   moments    fp32  [M, 4]  sum, sum of squares, max, count(sim >= count_thr)
@@ -209,7 +217,7 @@ int tvc_bank_gather(tvc_handle* h, const int32_t* idx_dev, int32_t n,
  * into the global top-k: parts are [W, M, k] (idx, sim) each sorted descending,
  * feat_parts fp32 [W, M, kf, D] or NULL carries the rows of the first kf
  * entries of every part; outputs as tvc_bank_search plus feat_out [M, kf, D].
- * mom_parts [W, M, 4] / mom_out [M, 4] may be NULL.
+ * mom_parts [W, M, 4] / mom_out [M, 4] may be NULL.  Limits: W * k <= 256, kf <= min(k, 32).
  * Replaces dist.all_gather + host merge (src/utils/multi_gpu_processor.py:595-612). */
 int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim_parts_dev,
                    const float* feat_parts_dev, const float* mom_parts_dev,
@@ -232,7 +240,9 @@ typedef struct {
     float   similarity_threshold; /* retrieval_ref.py:24 (0.3)                         */
     int32_t retrieval_top_k;      /* experiments/defenses/detector.py:29 (10), <= 16   */
     float   dup_threshold;        /* experiments/defenses/detector.py:318 (0.95)       */
-    float   w_text_variants;      /* src/detector.py:667 (0.4)                         */
+    float   w_text_variants;      /* src/detector.py:667 (0.4); 0 = method off.  With N == 0 and a weight > 0 the
+                                     method still enters the weighted mean with score 0.0 (augmenter present but
+                                     no variants, src/detector.py:375-378,457-458)                            */
     float   w_consistency;        /* src/detector.py:669 (0.2)                         */
     float   w_exp[4];             /* consistency_checker.py:61-66 (0.25 each): original,
                                      text_variant, retrieval, generative               */

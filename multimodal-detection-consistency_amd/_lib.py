@@ -18,6 +18,7 @@ HEADER_PATH = PKG_DIR.parent / "include" / "tvc.h"
 TVC_OK, TVC_E_INVALID, TVC_E_HIP, TVC_E_NOMEM, TVC_E_STATE, TVC_E_OVERFLOW = range(6)
 TVC_DTYPE_BF16, TVC_DTYPE_F32 = 0, 1
 TVC_REC_HEAD, TVC_REC_MAXREF = 12, 16
+TVC_ABI_VERSION, TVC_MAX_BANKS, TVC_MAX_TOPK = 2, 8, 128
 TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS, TVC_OPT_BANK_FILTER = 1, 2, 3, 4
 TVC_OPT_TEXT_GROUP = 5
 
@@ -75,6 +76,7 @@ SIGNATURES = {
     "tvc_encode_image": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_encode_text": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_bank_set": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "tvc_bank_select": (C.c_int, [_P, C.c_int32]),
     "tvc_bank_search": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P, _P, _P, _P]),
     "tvc_bank_search_dense": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int64, _P, _P, _P, _P]),
     "tvc_bank_status": (C.c_int, [_P, _P]),

@@ -48,18 +48,29 @@ class HashTokenizer:
     available (no network): lower-cased word / punctuation pieces are hashed into
     the id range [1, 49405]; SOT / EOT / padding follow the CLIP layout."""
 
+    _PIECES = re.compile(r"[a-z0-9]+|[^\sa-z0-9]")
+
     def __init__(self, ctx: int = 77):
         self.ctx = ctx
+        self._ids: Dict[str, int] = {}          # piece -> id (the hash is computed once per distinct piece)
+
+    def _id(self, piece: str) -> int:
+        v = self._ids.get(piece)
+        if v is None:
+            v = 1 + int.from_bytes(hashlib.blake2s(piece.encode(), digest_size=4).digest(), "little") % (synth.SOT - 1)
+            if len(self._ids) < 1_000_000:
+                self._ids[piece] = v
+        return v
 
     def __call__(self, texts: Sequence[str]) -> torch.Tensor:
         out = np.zeros((len(texts), self.ctx), dtype=np.int32)
+        out[:, 0] = synth.SOT
+        find, ident, cap = self._PIECES.findall, self._id, self.ctx - 2
         for i, t in enumerate(texts):
-            pieces = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", t.lower())[: self.ctx - 2]
-            ids = [1 + int.from_bytes(hashlib.blake2s(p.encode(), digest_size=4).digest(), "little") % (synth.SOT - 1)
-                   for p in pieces]
-            out[i, 0] = synth.SOT
-            out[i, 1:1 + len(ids)] = ids
-            out[i, 1 + len(ids)] = synth.EOT
+            ids = [ident(p) for p in find(t.lower())[:cap]]
+            m = len(ids)
+            out[i, 1:1 + m] = ids
+            out[i, 1 + m] = synth.EOT
         return torch.from_numpy(out)
 
 

@@ -17,6 +17,7 @@
 // statistics are per-lane scalars and the output is 8-byte row pieces.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <mutex>
 
 #define ATT_DH 64
 #define ATT_KROW 128     // K image: 64 bf16 per row
@@ -262,13 +263,13 @@ static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* 
     const int region = k_bytes + NP * 32 * ATT_VROW;
     constexpr int IPW = NW / WPS;
     const size_t lds = (size_t)region * IPW;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (st != hipSuccess) return st;
-        attr_done = true;
-    }
+    static std::once_flag attr_once;          // per instantiation; thread-safe
+    static hipError_t attr_st = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_st = hipFuncSetAttribute((const void*)attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
+    if (attr_st != hipSuccess) return attr_st;
     const int n_items = n_seq * heads;
     hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>), dim3((n_items + IPW - 1) / IPW), dim3(NW * 64), lds, stream,
                        qkv, out, starts, T, heads, n_items, k_bytes, region, pfx, n_seq);

@@ -31,6 +31,7 @@
 // three products hi.hi + lo.hi + hi.lo.
 #include "gemm_core.hpp"
 #include "kernels.hpp"
+#include <mutex>
 
 #define BANK_CAP 128
 #define BANK_KEFF 16       // tau = max(k, 16)-th largest group maximum: a looser but far less noisy bound
@@ -124,6 +125,9 @@ __global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict_
     if (rank == keff - 1) {
         float v = m;
         if (v > -INFINITY) v = v - 1e-6f - 1e-6f * fabsf(v) - margin;
+        // a NaN / inf margin (NaN or inf bank rows reach bank_bounds) must list every finite row:
+        // the lists overflow, tvc_bank_status reports it and the brute-force path takes over
+        if (!(v == v)) v = -INFINITY;
         tau[q] = v;
     }
 }
@@ -156,8 +160,8 @@ __global__ __launch_bounds__(256) void bank_bounds_kernel(const uint16_t* __rest
         mh = fmaxf(mh, wave_sum(h2)); ml = fmaxf(ml, wave_sum(l2));
     }
     if (lane == 0) {
-        // NaN/inf rows: the uint order puts them on top, the margin becomes inf/NaN and the
-        // filter lists everything (-> overflow flag -> brute-force path); never a wrong result
+        // NaN/inf rows: the uint order puts them on top, the margin becomes inf/NaN, tau = -inf and the
+        // filter lists every finite row (-> overflow flag -> brute-force path); never a wrong result
         atomicMax(out_sq, __float_as_uint(mh));
         atomicMax(out_sq + 1, __float_as_uint(ml));
     }
@@ -225,22 +229,27 @@ __device__ __forceinline__ void bank_tile_epilogue(const gemm_acc_t& acc, const 
                     for (int r = 0; r < 4; ++r) cn[n] += (v[r] >= e.count_thr) ? 1.f : 0.f;
                 }
             }
-            // NaN-safe: !(m4 <= tau) also lists rows when the bound is NaN (degenerate bank rows)
-            if (!(m4 <= tau[n])) {
+            // NaN similarities (zero-norm query row, NaN bank row) are never listed: every comparison
+            // with a NaN is false, and fmaxf drops NaN operands; tau itself is never NaN (kth_bound_kernel)
+            if (m4 > tau[n]) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (!(v[r] <= tau[n]) && (FULL || row + r < e.R)) {
+                    if (v[r] > tau[n] && (FULL || row + r < e.R)) {
                         // rare path (a few survivors per lane per bank chunk): keep
                         // its address arithmetic inside the branch, not hoisted into
                         // registers that stay live across the main loop
                         int qlo = ql;
                         asm volatile("" : "+v"(qlo));
-                        const int slot = atomicAdd(&lds_cnt[qlo], 1);
-                        if (slot < BANK_CAP) {
-                            Cand c;
-                            c.v = v[r];
-                            c.idx = (int32_t)(row + r + e.idx_offset);
-                            e.cand[((int64_t)chunk * e.M + (j0 + qlo)) * BANK_CAP + slot] = c;
+                        // padded query lanes (q >= M) re-read the last query row with tau = +inf and never get
+                        // here; the guard keeps a stray append out of the lists of (chunk + 1, q - M)
+                        if (j0 + qlo < e.M) {
+                            const int slot = atomicAdd(&lds_cnt[qlo], 1);
+                            if (slot < BANK_CAP) {
+                                Cand c;
+                                c.v = v[r];
+                                c.idx = (int32_t)(row + r + e.idx_offset);
+                                e.cand[((int64_t)chunk * e.M + (j0 + qlo)) * BANK_CAP + slot] = c;
+                            }
                         }
                     }
                 }
@@ -527,7 +536,8 @@ __global__ __launch_bounds__(1024) void row_topk_kernel(float* __restrict__ sims
         bool has = false;
         for (int64_t i = t; i < R; i += 1024) {
             const float v = row[i];
-            if (v != -INFINITY && (!has || v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; has = true; }
+            // NaN similarities (NaN bank rows / zero-norm queries) are never returned
+            if (v == v && v != -INFINITY && (!has || v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; has = true; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -580,16 +590,17 @@ hipError_t launch_bank_search_dense(const BankSearchLaunch& L, float* sims_ws, i
 }
 
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t st = hipFuncSetAttribute((const void*)bank_search_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
-        if (st != hipSuccess) return st;
-        st = hipFuncSetAttribute((const void*)bank_search_kernel<true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
-        if (st != hipSuccess) return st;
-        attr_done = true;
-    }
+    // thread-safe one-time setup (two engines may launch their first search from two threads)
+    static std::once_flag attr_once;
+    static hipError_t attr_st = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_st = hipFuncSetAttribute((const void*)bank_search_kernel<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
+        if (attr_st == hipSuccess)
+            attr_st = hipFuncSetAttribute((const void*)bank_search_kernel<true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
+    });
+    if (attr_st != hipSuccess) return attr_st;
     const int D = L.D;
     // products: (bank plane, query plane) pairs accumulated into one tile
     //   bf16 bank : b.qhi + b.qlo
@@ -725,7 +736,7 @@ hipError_t launch_topk_merge(const int32_t* idx_parts, const float* sim_parts, c
                              int32_t* idx_out, float* sim_out, float* feat_out, float* mom_out,
                              hipStream_t stream) {
     if (M == 0) return hipSuccess;
-    if (W < 1 || k < 1 || k > 32 || W * k > 256 || kf < 0 || kf > k) return hipErrorInvalidValue;
+    if (W < 1 || k < 1 || k > 128 || W * k > 256 || kf < 0 || kf > k || kf > 32) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(M), dim3(256), 0, stream, idx_parts, sim_parts, feat_parts,
                        mom_parts, W, M, k, kf, D, idx_out, sim_out, feat_out, mom_out);
     return hipGetLastError();

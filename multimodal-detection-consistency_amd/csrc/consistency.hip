@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256) void consistency_kernel(const float* __restric
         const double variability = 1.0 - sd;
         const double tv = 1.0 - (consistency * 0.7 + variability * 0.3);
         const double cs = 1.0 - s0;
-        double agg;
-        if (N > 0) agg = (tv * P.w_text_variants + cs * P.w_consistency) / ((double)P.w_text_variants + P.w_consistency);
-        else agg = cs;
+        // A requested method whose component exists but yields nothing still enters the weighted mean
+        // with its 0.0 score (src/detector.py:375-378,457-458): N == 0 with w_text_variants > 0 gives
+        // (0.4 * 0 + 0.2 * cs) / 0.6.  The caller passes w_text_variants = 0 when the method is off.
+        const double tv_eff = (N > 0) ? tv : 0.0;
+        const double wsum = (double)P.w_text_variants + (double)P.w_consistency;
+        const double agg = wsum > 0.0 ? (tv_eff * P.w_text_variants + cs * P.w_consistency) / wsum : 0.0;
         // exp polarity (experiments/defenses/detector.py:251-300)
         double rmean = 0.0, rsd = 0.0;
         if (nu > 0) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void consistency_kernel(const float* __restric
         for (int i = 0; i < 4; ++i) if (four[i] > 0) { ws += four[i] * P.w_exp[i]; tw += P.w_exp[i]; }
         const double overall = (tw != 0.0) ? ws / tw : 0.0;
 
-        r[0] = (float)s0; r[1] = (float)mean; r[2] = (float)sd; r[3] = (float)tv; r[4] = (float)cs;
+        r[0] = (float)s0; r[1] = (float)mean; r[2] = (float)sd; r[3] = (float)tv_eff; r[4] = (float)cs;
         r[5] = (float)agg; r[6] = (float)rmean; r[7] = (float)rsd; r[8] = (float)nu; r[9] = (float)xvar;
         r[10] = (float)overall; r[11] = 0.f;
         for (int n = 0; n < N; ++n) r[12 + n] = sims[n + 1];

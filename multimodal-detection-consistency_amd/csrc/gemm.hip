@@ -2,6 +2,7 @@
 // bank-search pre-pass.  See gemm_core.hpp for the tiling.
 #include "gemm_epilogue.hpp"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 // s_setprio levels of the MFMA phases of the two wave groups of the ring kernel (see gemm_ring_kernel)
@@ -279,11 +280,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_finish_kernel(GemmOp
     if (i < g.I && j < g.J) gemm_store4<EPI>(e, g.I, i, j, v);
 }
 
+static hipError_t set_lds_attr_impl();
 static hipError_t set_lds_attr_once() {
-    static bool done = false;
+    // thread-safe: the Python lock is per engine, two engines may first-launch from two threads
+    static std::once_flag once;
     static hipError_t st = hipSuccess;
-    if (done) return st;
-    done = true;
+    std::call_once(once, [] { st = set_lds_attr_impl(); });
+    return st;
+}
+static hipError_t set_lds_attr_impl() {
+    hipError_t st = hipSuccess;
 #define SET_ATTR(K)                                                                              \
     if (st == hipSuccess)                                                                        \
         st = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize,     \

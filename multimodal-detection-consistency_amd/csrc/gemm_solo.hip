@@ -1,6 +1,7 @@
 // Four-wave (one wave per SIMD) persistent bf16 GEMM: see the kernel comment.  Own translation
 // unit: the 256-accumulator kernel takes a while to compile.
 #include "gemm_epilogue.hpp"
+#include <mutex>
 
 // ---------------------------------------------------------------------------
 // Four-wave variant: ONE wave per SIMD owns a 128 x 128 quarter of the 256 x 256 tile
@@ -267,19 +268,16 @@ void gemm_solo_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
 
 hipError_t launch_gemm_solo(const GemmOperands& g, const GemmEpilogue& e, int epilogue, int nIt, int nJt,
                             hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t st = hipSuccess;
-#define SET_ATTR(K)                                                                              \
-    if (st == hipSuccess)                                                                        \
-        st = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                 SOLO_LDS_BYTES);
-        SET_ATTR(gemm_solo_kernel<TVC_EPI_BF16>)
-        SET_ATTR(gemm_solo_kernel<TVC_EPI_GELU_BF16>)
-#undef SET_ATTR
-        if (st != hipSuccess) return st;
-        attr_done = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_st = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_st = hipFuncSetAttribute((const void*)gemm_solo_kernel<TVC_EPI_BF16>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SOLO_LDS_BYTES);
+        if (attr_st == hipSuccess)
+            attr_st = hipFuncSetAttribute((const void*)gemm_solo_kernel<TVC_EPI_GELU_BF16>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, SOLO_LDS_BYTES);
+    });
+    if (attr_st != hipSuccess) return attr_st;
     const int ntiles = nIt * nJt;
     const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles / 8) * 8);
     const dim3 sblock(SOLO_THREADS);

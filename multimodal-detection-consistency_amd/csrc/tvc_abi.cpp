@@ -31,6 +31,15 @@ struct Buf {
     size_t n = 0;
 };
 
+struct BankSlot {
+    const uint16_t* bank = nullptr;
+    void* owned = nullptr;            // (hi | lo) planes of an fp32 bank
+    int64_t R = 0;
+    int D = 0;
+    int planes = 1;
+    float* bounds = nullptr;          // device [2]: max row norms of the bank planes
+};
+
 struct ProfRec {
     hipEvent_t a, b;
     int cat;
@@ -45,13 +54,10 @@ struct tvc_handle {
     tvc_vision_weights vw{};
     tvc_text_weights tw{};
     std::vector<tvc_layer_weights> vlayers, tlayers;
-    // bank
-    const uint16_t* bank = nullptr;
-    void* bank_owned = nullptr;
-    int64_t R = 0;
-    int D = 0;
-    int bank_planes = 1;
-    float* bank_bounds = nullptr;     // device [2]: max row norms of the bank planes
+    // banks: TVC_MAX_BANKS independent slots (retriever index, reference bank, defense references ...
+    // registered by different owners on one engine); tvc_bank_select picks the one the bank calls address
+    BankSlot banks[TVC_MAX_BANKS];
+    int cur_bank = 0;
     bool bank_filter = true;          // TVC_OPT_BANK_FILTER
     Buf ws[WS_COUNT];
     std::string err;
@@ -257,8 +263,10 @@ int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision, con
 void tvc_destroy(tvc_handle* h) {
     if (!h) return;
     for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
-    if (h->bank_owned) (void)hipFree(h->bank_owned);
-    if (h->bank_bounds) (void)hipFree(h->bank_bounds);
+    for (auto& bk : h->banks) {
+        if (bk.owned) (void)hipFree(bk.owned);
+        if (bk.bounds) (void)hipFree(bk.bounds);
+    }
     delete h;
 }
 
@@ -375,25 +383,33 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
 
 int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D, int32_t dtype, void* stream) {
     if (!h) return TVC_E_INVALID;
+    BankSlot& bk = h->banks[h->cur_bank];
     if (R < 0 || R > 0x7fffffffLL || D <= 0 || D % 64 != 0 || (R > 0 && !bank_dev))
         return fail(h, TVC_E_INVALID, "tvc_bank_set: need 0 <= R < 2^31 and D % 64 == 0");
-    if (h->bank_owned) { HIP_TRY(hipFree(h->bank_owned)); h->bank_owned = nullptr; }
-    h->bank = nullptr; h->R = 0; h->D = D;
+    if (bk.owned) { HIP_TRY(hipFree(bk.owned)); bk.owned = nullptr; }
+    bk.bank = nullptr; bk.R = 0; bk.D = D;
     if (dtype == TVC_DTYPE_BF16) {
-        h->bank = (const uint16_t*)bank_dev; h->bank_planes = 1;
+        bk.bank = (const uint16_t*)bank_dev; bk.planes = 1;
     } else if (dtype == TVC_DTYPE_F32) {
         if (R > 0) {
-            HIP_TRY(hipMalloc(&h->bank_owned, (size_t)R * 2 * D * 2));
-            HIP_TRY(launch_split_planes((const float*)bank_dev, (uint16_t*)h->bank_owned, R, D, 2, (hipStream_t)stream));
+            HIP_TRY(hipMalloc(&bk.owned, (size_t)R * 2 * D * 2));
+            HIP_TRY(launch_split_planes((const float*)bank_dev, (uint16_t*)bk.owned, R, D, 2, (hipStream_t)stream));
         }
-        h->bank = (const uint16_t*)h->bank_owned; h->bank_planes = 2;
+        bk.bank = (const uint16_t*)bk.owned; bk.planes = 2;
     } else {
         return fail(h, TVC_E_INVALID, "tvc_bank_set: dtype must be TVC_DTYPE_BF16 or TVC_DTYPE_F32");
     }
-    if (!h->bank_bounds) HIP_TRY(hipMalloc((void**)&h->bank_bounds, 8));
-    HIP_TRY(launch_bank_bounds(h->bank, (int64_t)h->bank_planes * D, h->bank_planes, D, R, h->bank_bounds,
+    if (!bk.bounds) HIP_TRY(hipMalloc((void**)&bk.bounds, 8));
+    HIP_TRY(launch_bank_bounds(bk.bank, (int64_t)bk.planes * D, bk.planes, D, R, bk.bounds,
                                (hipStream_t)stream));
-    h->R = R;
+    bk.R = R;
+    return TVC_OK;
+}
+
+int tvc_bank_select(tvc_handle* h, int32_t slot) {
+    if (!h) return TVC_E_INVALID;
+    if (slot < 0 || slot >= TVC_MAX_BANKS) return fail(h, TVC_E_INVALID, "tvc_bank_select: slot must be in [0, TVC_MAX_BANKS)");
+    h->cur_bank = slot;
     return TVC_OK;
 }
 
@@ -401,14 +417,15 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
                     int64_t idx_offset, int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
                     void* stream) {
     if (!h) return TVC_E_INVALID;
-    if (!h->bank && h->R != 0) return fail(h, TVC_E_STATE, "tvc_bank_search: no bank registered");
-    if (h->D == 0) return fail(h, TVC_E_STATE, "tvc_bank_search: call tvc_bank_set first");
-    if (M < 0 || k < 1 || k > 32 || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
-        return fail(h, TVC_E_INVALID, "tvc_bank_search: need 1 <= k <= 32 and non-NULL buffers");
+    BankSlot& bk = h->banks[h->cur_bank];
+    if (!bk.bank && bk.R != 0) return fail(h, TVC_E_STATE, "tvc_bank_search: no bank registered");
+    if (bk.D == 0) return fail(h, TVC_E_STATE, "tvc_bank_search: call tvc_bank_set first");
+    if (M < 0 || k < 1 || k > TVC_MAX_TOPK || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_bank_search: need 1 <= k <= 128 and non-NULL buffers");
     if (M == 0) return TVC_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int D = h->D;
-    if (h->R == 0) {
+    const int D = bk.D;
+    if (bk.R == 0) {
         // empty bank: retrieval_ref.py:195-197 returns no references
         HIP_TRY(hipMemsetAsync(topk_idx_dev, 0xff, (size_t)M * k * 4, st));
         HIP_TRY(hipMemsetAsync(topk_sim_dev, 0, (size_t)M * k * 4, st));
@@ -416,7 +433,7 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
         return TVC_OK;
     }
     BankSearchLaunch L;
-    bank_plan(h->R, M, k, &L.n_sample, &L.sample_stride, &L.S, &L.cap);
+    bank_plan(bk.R, M, k, &L.n_sample, &L.sample_stride, &L.S, &L.cap);
     int rc;
     if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
     if ((rc = ensure(h, WS_S0, (size_t)M * L.n_sample * 4))) return rc;
@@ -426,18 +443,18 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     if ((rc = ensure(h, WS_MOM_PART, (size_t)L.S * M * 16))) return rc;
     if ((rc = ensure(h, WS_OVERFLOW, 16))) return rc;
     HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
-    L.bank = h->bank; L.ldb = (int64_t)h->bank_planes * D; L.R = h->R; L.D = D; L.bank_planes = h->bank_planes;
+    L.bank = bk.bank; L.ldb = (int64_t)bk.planes * D; L.R = bk.R; L.D = D; L.bank_planes = bk.planes;
     L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
-    L.rows = rows_dev; L.bank_bounds = h->bank_bounds; L.allow_filter = h->bank_filter;
+    L.rows = rows_dev; L.bank_bounds = bk.bounds; L.allow_filter = h->bank_filter;
     L.s0 = (float*)h->ws[WS_S0].p; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
     L.cand_cnt = (int32_t*)h->ws[WS_CAND_CNT].p; L.mom_part = (float*)h->ws[WS_MOM_PART].p;
     L.overflow = (int32_t*)h->ws[WS_OVERFLOW].p;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
     {
         const bool filter = !moments_dev && h->bank_filter && D <= 2048;
-        const int planes = filter ? 1 : (h->bank_planes == 2 ? 3 : 2);
-        ProfScope ps(h, st, TVC_PROF_BANK, 2.0 * (double)h->R * M * D * planes);
+        const int planes = filter ? 1 : (bk.planes == 2 ? 3 : 2);
+        ProfScope ps(h, st, TVC_PROF_BANK, 2.0 * (double)bk.R * M * D * planes);
         HIP_TRY(launch_bank_search(L, st));
     }
     return TVC_OK;
@@ -447,22 +464,23 @@ int tvc_bank_search_dense(tvc_handle* h, const float* rows_dev, int32_t M, int32
                           int64_t idx_offset, int32_t* topk_idx_dev, float* topk_sim_dev, float* moments_dev,
                           void* stream) {
     if (!h) return TVC_E_INVALID;
-    if (h->D == 0 || (!h->bank && h->R != 0)) return fail(h, TVC_E_STATE, "tvc_bank_search_dense: call tvc_bank_set first");
-    if (M < 0 || k < 1 || k > 32 || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
-        return fail(h, TVC_E_INVALID, "tvc_bank_search_dense: need 1 <= k <= 32 and non-NULL buffers");
+    BankSlot& bk = h->banks[h->cur_bank];
+    if (bk.D == 0 || (!bk.bank && bk.R != 0)) return fail(h, TVC_E_STATE, "tvc_bank_search_dense: call tvc_bank_set first");
+    if (M < 0 || k < 1 || k > TVC_MAX_TOPK || (M > 0 && (!rows_dev || !topk_idx_dev || !topk_sim_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_bank_search_dense: need 1 <= k <= 128 and non-NULL buffers");
     if (M == 0) return TVC_OK;
-    if (h->R == 0) return tvc_bank_search(h, rows_dev, M, k, count_thr, idx_offset, topk_idx_dev, topk_sim_dev, moments_dev, stream);
+    if (bk.R == 0) return tvc_bank_search(h, rows_dev, M, k, count_thr, idx_offset, topk_idx_dev, topk_sim_dev, moments_dev, stream);
     hipStream_t st = (hipStream_t)stream;
-    const int D = h->D;
-    int block = (int)((size_t)1 << 28) / (int)(h->R > 0 ? h->R : 1);      // <= 1 GiB of similarities at a time
+    const int D = bk.D;
+    int block = (int)((size_t)1 << 28) / (int)(bk.R > 0 ? bk.R : 1);      // <= 1 GiB of similarities at a time
     if (block > 64) block = 64;
     if (block < 1) block = 1;
     int rc;
     if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
-    if ((rc = ensure(h, WS_S0, (size_t)block * h->R * 4))) return rc;
+    if ((rc = ensure(h, WS_S0, (size_t)block * bk.R * 4))) return rc;
     HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
     BankSearchLaunch L;
-    L.bank = h->bank; L.ldb = (int64_t)h->bank_planes * D; L.R = h->R; L.D = D; L.bank_planes = h->bank_planes;
+    L.bank = bk.bank; L.ldb = (int64_t)bk.planes * D; L.R = bk.R; L.D = D; L.bank_planes = bk.planes;
     L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
@@ -488,11 +506,12 @@ int tvc_bank_status(tvc_handle* h, void* stream) {
 int tvc_bank_gather(tvc_handle* h, const int32_t* idx_dev, int32_t n, int64_t idx_offset, float* out_dev,
                     void* stream) {
     if (!h) return TVC_E_INVALID;
-    if (h->D == 0) return fail(h, TVC_E_STATE, "tvc_bank_gather: call tvc_bank_set first");
+    BankSlot& bk = h->banks[h->cur_bank];
+    if (bk.D == 0) return fail(h, TVC_E_STATE, "tvc_bank_gather: call tvc_bank_set first");
     if (n < 0 || (n > 0 && (!idx_dev || !out_dev))) return fail(h, TVC_E_INVALID, "tvc_bank_gather: bad arguments");
     if (n == 0) return TVC_OK;
-    if (h->R == 0) { HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n * h->D * 4, (hipStream_t)stream)); return TVC_OK; }
-    HIP_TRY(launch_gather_rows(h->bank, (int64_t)h->bank_planes * h->D, h->bank_planes, h->D, h->R, idx_dev,
+    if (bk.R == 0) { HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n * bk.D * 4, (hipStream_t)stream)); return TVC_OK; }
+    HIP_TRY(launch_gather_rows(bk.bank, (int64_t)bk.planes * bk.D, bk.planes, bk.D, bk.R, idx_dev,
                                idx_offset, n, out_dev, (hipStream_t)stream));
     return TVC_OK;
 }

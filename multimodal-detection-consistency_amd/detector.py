@@ -127,6 +127,11 @@ class AdversarialDetector:
         return as_generator(self.text_augmenter, self.config.num_text_variants)(text)
 
     # -- batched core --------------------------------------------------------
+    def _src_cfg(self, text_variants_on: bool) -> ConsistencyConfig:
+        """Weights of the device-side weighted mean (src/detector.py:666-670); weight 0 = method off."""
+        return ConsistencyConfig(w_text_variants=SRC_WEIGHTS["text_variants"] if text_variants_on else 0.0,
+                                 w_consistency=SRC_WEIGHTS["consistency"])
+
     def detect_tokens(self, images: torch.Tensor, tokens: torch.Tensor) -> Dict[str, np.ndarray]:
         """images [B,3,S,S], tokens int [B, N+1, ctx] (row 0 = original text) ->
         host arrays of the record fields (see ``unpack_records``) plus
@@ -136,7 +141,7 @@ class AdversarialDetector:
         B, N1, ctx = tokens.shape
         fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
         ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True, group=N1)
-        rec = clip.engine.consistency(fi, ft.view(B, N1, -1), ConsistencyConfig())
+        rec = clip.engine.consistency(fi, ft.view(B, N1, -1), self._src_cfg(self.config.use_text_variants))
         out = unpack_records(rec, N1 - 1)
         out["aggregated_score"] = out["score_src"]
         out["is_adversarial"] = out["score_src"] > self.config.detection_threshold      # src/detector.py:399
@@ -145,78 +150,117 @@ class AdversarialDetector:
     def batch_detect(self, images, texts: Sequence[str], methods: Optional[List[str]] = None,
                      variants: Optional[Sequence[Sequence[str]]] = None,
                      reference_images: Optional[Sequence[Sequence[Any]]] = None) -> List[Dict[str, Any]]:
-        """src/detector.py:711-734, truly batched.  Queries are grouped by their
-        variant count so every group is one launch."""
+        """src/detector.py:711-734, truly batched.  Queries are grouped by their variant count so
+        every group is one launch; ALL device work (image tower, text tower, reference-image tower,
+        consistency kernels) is enqueued before the first device-to-host copy, and the host
+        tokenises while the GPU runs the image tower."""
         methods = methods or self.config.detection_methods
         t0 = time.time()
         clip = self._get_clip_model()
+        eng = clip.engine
         if isinstance(images, torch.Tensor) and images.dim() == 3:
             images = images.unsqueeze(0)
         n = len(texts)
-        if variants is None:
-            variants = [self._variants(t) if "text_variants" in methods else [] for t in texts]
         x, _ = clip._images_to_device(images if isinstance(images, torch.Tensor) else list(images))
         if x.shape[0] != n:
             raise ValueError("number of images and texts differ")
-        fi = clip.engine.encode_image(x, True)
-        results: List[Optional[Dict[str, Any]]] = [None] * n
+        fi = eng.encode_image(x, True)                      # enqueued first: overlaps the host work below
+        # a requested method is scored whenever its component exists (src/detector.py:375,382), also when
+        # the component yields nothing for a query (0.0 + 'error', :457-458, :524-525)
+        tv_on = "text_variants" in methods and self.config.use_text_variants
+        sd_on = "sd_reference" in methods and (reference_images is not None or self.sd_generator is not None)
+        if variants is None:
+            variants = [self._variants(t) if tv_on else [] for t in texts]
         groups: Dict[int, List[int]] = {}
         for i, v in enumerate(variants):
             groups.setdefault(len(v), []).append(i)
+        cfg = self._src_cfg(tv_on)
+        pending = []                                        # (N, ids, device records)
         for N, ids in groups.items():
-            flat = []
+            flat: List[str] = []
             for i in ids:
                 flat.append(texts[i])
                 flat.extend(variants[i])
-            tok = clip.tokenize(flat)
-            ft = clip.encode_tokens(tok, True, group=N + 1).view(len(ids), N + 1, -1)
-            sel = torch.as_tensor(ids, device=fi.device)
-            rec = unpack_records(clip.engine.consistency(fi[sel].contiguous(), ft, ConsistencyConfig()), N)
-            for j, i in enumerate(ids):
-                scores, details = {}, {}
-                if "text_variants" in methods and N > 0:
-                    scores["text_variants"] = float(rec["score_text_variants"][j])
-                    details["text_variants"] = {
-                        "original_similarity": float(rec["original_similarity"][j]),
-                        "variant_similarities": rec["variant_similarities"][j].tolist(),
-                        "mean_variant_similarity": float(rec["variant_mean"][j]),
-                        "std_variant_similarity": float(rec["variant_std"][j]),
-                        "consistency_score": float(1.0 - abs(rec["original_similarity"][j] - rec["variant_mean"][j])),
-                        "variability_score": float(1.0 - rec["variant_std"][j]),
-                        "num_variants": N,
-                    }
-                if "consistency" in methods:
-                    scores["consistency"] = float(rec["score_consistency"][j])
-                    details["consistency"] = {"image_text_similarity": float(rec["original_similarity"][j]),
-                                              "consistency_score": float(rec["original_similarity"][j])}
-                results[i] = {"detection_scores": scores, "detection_details": details}
-        # SD-reference method: arithmetic in scope (src/detector.py:528-553), producing the
-        # reference images is not -- they come from the caller or an injected generator
-        if "sd_reference" in methods:
+            ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
+            sel = fi if len(ids) == n else fi[torch.as_tensor(ids, device=fi.device)].contiguous()
+            pending.append((N, ids, eng.consistency(sel, ft, cfg)))
+        # SD-reference method: arithmetic in scope (src/detector.py:528-553), producing the reference
+        # images is not -- they come from the caller or an injected generator.  ONE encode of all
+        # reference images, one consistency launch per distinct count (cos(image, ref_j) = record words 0, 12..).
+        sd_pending, sd_counts = [], [0] * n
+        if sd_on:
+            per_q = []
             for i in range(n):
-                refs = None
                 if reference_images is not None:
                     refs = reference_images[i]
-                elif self.sd_generator is not None:
+                else:
                     refs = self.sd_generator.generate_reference_images(
                         texts[i], num_images=self.config.num_reference_images).get("images", [])
-                if refs:
-                    xr, _ = clip._images_to_device(list(refs))
-                    fr = clip.engine.encode_image(xr, True)
-                    r = unpack_records(clip.engine.consistency(fi[i:i + 1], fr.unsqueeze(0), ConsistencyConfig()),
-                                       fr.shape[0] - 1)
-                    sims = np.concatenate([[r["original_similarity"][0]], r["variant_similarities"][0]])
-                    results[i]["detection_scores"]["sd_reference"] = float(1.0 - sims.mean())
-                    results[i]["detection_details"]["sd_reference"] = {
-                        "reference_similarities": sims.tolist(), "mean_similarity": float(sims.mean()),
-                        "max_similarity": float(sims.max()), "std_similarity": float(sims.std()),
-                        "num_references": int(sims.size)}
+                per_q.append(list(refs) if refs is not None else [])
+            sd_counts = [len(r) for r in per_q]
+            all_refs = [im for r in per_q for im in r]
+            if all_refs:
+                xr, _ = clip._images_to_device(all_refs)
+                fr = eng.encode_image(xr, True)
+                offs = np.concatenate([[0], np.cumsum(sd_counts)])
+                by_count: Dict[int, List[int]] = {}
+                for i, c in enumerate(sd_counts):
+                    if c:
+                        by_count.setdefault(c, []).append(i)
+                for J, ids in by_count.items():
+                    rows = torch.as_tensor(np.concatenate([np.arange(offs[i], offs[i] + J) for i in ids]), device=fr.device)
+                    qsel = torch.as_tensor(ids, device=fi.device)
+                    sd_pending.append((J, ids, eng.consistency(fi[qsel].contiguous(), fr[rows].view(len(ids), J, -1), cfg)))
+
+        # ---- device -> host, then plain-Python result construction (lists, no per-field numpy scalar)
+        scores: List[Dict[str, float]] = [dict() for _ in range(n)]
+        details: List[Dict[str, Any]] = [dict() for _ in range(n)]
+        cons_rows: List[Any] = [None] * n
+        for N, ids, rec_dev in pending:
+            r = rec_dev.cpu().numpy().astype(np.float64)
+            s0, mean, sd, tv, cs = (r[:, c].tolist() for c in range(5))
+            sv = r[:, 12:12 + N].tolist()
+            for j, i in enumerate(ids):
+                if tv_on:
+                    if N > 0:
+                        scores[i]["text_variants"] = tv[j]
+                        details[i]["text_variants"] = {
+                            "original_similarity": s0[j], "variant_similarities": sv[j],
+                            "mean_variant_similarity": mean[j], "std_variant_similarity": sd[j],
+                            "consistency_score": 1.0 - abs(s0[j] - mean[j]), "variability_score": 1.0 - sd[j],
+                            "num_variants": N}
+                    else:
+                        scores[i]["text_variants"] = 0.0                                 # :457-458
+                        details[i]["text_variants"] = {"error": "no text variants"}
+                cons_rows[i] = (cs[j], s0[j])
+        if sd_on:
+            for i in range(n):
+                if sd_counts[i] == 0:
+                    scores[i]["sd_reference"] = 0.0                                      # :524-525
+                    details[i]["sd_reference"] = {"error": "no reference images"}
+            for J, ids, rec_dev in sd_pending:
+                r = rec_dev.cpu().numpy().astype(np.float64)
+                sims = np.concatenate([r[:, 0:1], r[:, 12:12 + J - 1]], axis=1)
+                mean, mx, sd = sims.mean(1).tolist(), sims.max(1).tolist(), sims.std(1).tolist()
+                sl = sims.tolist()
+                for j, i in enumerate(ids):
+                    scores[i]["sd_reference"] = 1.0 - mean[j]
+                    details[i]["sd_reference"] = {"reference_similarities": sl[j], "mean_similarity": mean[j],
+                                                  "max_similarity": mx[j], "std_similarity": sd[j], "num_references": J}
+        if "consistency" in methods:
+            for i in range(n):
+                cs, s0 = cons_rows[i]
+                scores[i]["consistency"] = cs
+                details[i]["consistency"] = {"image_text_similarity": s0, "consistency_score": s0}
         dt = time.time() - t0
-        for res in results:
-            agg = aggregate_scores(res["detection_scores"], self.config.score_aggregation)
-            res.update({"is_adversarial": bool(agg > self.config.detection_threshold),
-                        "aggregated_score": float(agg), "detection_time": dt / max(n, 1),
-                        "methods_used": methods, "threshold": self.config.detection_threshold})
+        per_q_dt = dt / max(n, 1)
+        thr, how = self.config.detection_threshold, self.config.score_aggregation
+        results = []
+        for i in range(n):
+            agg = aggregate_scores(scores[i], how)
+            results.append({"is_adversarial": bool(agg > thr), "aggregated_score": float(agg),
+                            "detection_scores": scores[i], "detection_details": details[i],
+                            "detection_time": per_q_dt, "methods_used": methods, "threshold": thr})
         with self._lock:
             self.detection_stats["total_detections"] += n
             self.detection_stats["detection_time"] += dt
@@ -382,13 +426,23 @@ class MultiModalDefenseDetector:
         self.config = config or DetectionConfig()
         self.text_variant_generator = text_generator if text_generator is not None else qwen_model
         self.retrieval_generator = retrieval_generator
+        # this detector's own bank slot on the (shared) engine; an injected RetrievalReferenceGenerator
+        # brings its registered features.npy rows with it
+        self.bank_name = getattr(retrieval_generator, "bank_name", None) or f"defense:{id(self):x}"
         self.consistency_checker = ConsistencyChecker(threshold=self.config.consistency_threshold,
                                                       adaptive_threshold=self.config.adaptive_threshold,
                                                       voting_strategy=self.config.voting_strategy)
 
+    def __del__(self):          # a bank this detector registered itself goes back to the shared engine
+        try:
+            if getattr(self.retrieval_generator, "bank_name", None) != self.bank_name:
+                self.clip_model.engine.release_bank(self.bank_name)
+        except Exception:
+            pass
+
     def set_reference_bank(self, features: torch.Tensor) -> None:
         """features [R, D] L2-normalised (``features.npy``, retrieval_ref.py:99)."""
-        self.clip_model.engine.set_bank(features.to(self.clip_model.device))
+        self.clip_model.engine.set_bank(features.to(self.clip_model.device), name=self.bank_name)
 
     def _cons_cfg(self) -> ConsistencyConfig:
         c = self.config
@@ -406,53 +460,52 @@ class MultiModalDefenseDetector:
         B, N1, ctx = tokens.shape
         fi = clip.engine.encode_image(images.to(clip.device, torch.float32), True)
         ft = clip.engine.encode_text(tokens.reshape(B * N1, ctx).to(clip.device, torch.int32), True, group=N1)
-        use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
-        rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank, robust=True)
+        use_bank = self.config.use_retrieval_ref and clip.engine.bank_size(self.bank_name) > 0
+        rec = clip.engine.detect_embeddings(fi, ft.view(B, N1, -1), self._cons_cfg(), use_bank=use_bank, robust=True,
+                                            bank=self.bank_name)
         return unpack_records(rec, N1 - 1)
-
-    @staticmethod
-    def _score_dict(rec: Dict[str, np.ndarray], j: int, has_variants: bool) -> Dict[str, float]:
-        s0 = float(rec["original_similarity"][j])
-        return {
-            "original_similarity": s0,
-            "text_variant_consistency": float(rec["variant_mean"][j]) if has_variants else s0,
-            "text_variant_std": float(rec["variant_std"][j]) if has_variants else 0.0,
-            "retrieval_consistency": float(rec["retrieval_consistency"][j]),
-            "retrieval_std": float(rec["retrieval_std"][j]),
-            "generative_consistency": 0.0, "generative_std": 0.0,       # generation out of scope
-            "cross_modal_variance": float(rec["cross_modal_variance"][j]),
-        }
 
     def batch_detect(self, images: torch.Tensor, texts: Sequence[str], return_details: bool = False,
                      variants: Optional[Sequence[Sequence[str]]] = None) -> List[Dict[str, Any]]:
         """experiments/defenses/detector.py:327-351, batched; decisions are taken
         in input order (the checker is stateful)."""
         clip = self.clip_model
+        eng = clip.engine
         n = len(texts)
+        x, _ = clip._images_to_device(images)
+        fi = eng.encode_image(x, True)                      # enqueued first: overlaps the host work below
         if variants is None:
             variants = [self._variants(t) for t in texts]
-        x, _ = clip._images_to_device(images)
-        fi = clip.engine.encode_image(x, True)
         per_query: List[Optional[Dict[str, float]]] = [None] * n
         extra: List[Optional[Dict]] = [None] * n
         groups: Dict[int, List[int]] = {}
         for i, v in enumerate(variants):
             groups.setdefault(len(v), []).append(i)
-        use_bank = self.config.use_retrieval_ref and clip.engine.bank_rows > 0
+        use_bank = self.config.use_retrieval_ref and eng.bank_size(self.bank_name) > 0
         for N, ids in groups.items():
-            flat = []
+            flat: List[str] = []
             for i in ids:
                 flat.append(texts[i])
                 flat.extend(variants[i])
             ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
-            sel = torch.as_tensor(ids, device=fi.device)
-            rec = unpack_records(clip.engine.detect_embeddings(fi[sel].contiguous(), ft, self._cons_cfg(), use_bank,
-                                                               robust=True), N)
+            sel = fi if len(ids) == n else fi[torch.as_tensor(ids, device=fi.device)].contiguous()
+            rec = unpack_records(eng.detect_embeddings(sel, ft, self._cons_cfg(), use_bank, robust=True,
+                                                       bank=self.bank_name), N)
+            s0 = rec["original_similarity"].tolist()
+            vm, vs = rec["variant_mean"].tolist(), rec["variant_std"].tolist()
+            rc, rs = rec["retrieval_consistency"].tolist(), rec["retrieval_std"].tolist()
+            xv, nref = rec["cross_modal_variance"].tolist(), rec["n_references"].tolist()
+            ridx, rsim = rec["reference_indices"].tolist(), rec["reference_similarities"].tolist()
             for j, i in enumerate(ids):
-                per_query[i] = self._score_dict(rec, j, N > 0)
-                k = int(rec["n_references"][j])
-                extra[i] = {"retrieval_references": rec["reference_indices"][j, :k].tolist(),
-                            "retrieval_similarities": rec["reference_similarities"][j, :k].tolist()}
+                per_query[i] = {
+                    "original_similarity": s0[j],
+                    "text_variant_consistency": vm[j] if N > 0 else s0[j],
+                    "text_variant_std": vs[j] if N > 0 else 0.0,
+                    "retrieval_consistency": rc[j], "retrieval_std": rs[j],
+                    "generative_consistency": 0.0, "generative_std": 0.0,       # generation out of scope (SURVEY.md 8f)
+                    "cross_modal_variance": xv[j]}
+                k = nref[j]
+                extra[i] = {"retrieval_references": ridx[j][:k], "retrieval_similarities": rsim[j][:k]}
         out = []
         for i in range(n):
             d = self.consistency_checker.make_decision(per_query[i], return_details=return_details)
@@ -474,5 +527,5 @@ class MultiModalDefenseDetector:
     def get_statistics(self) -> Dict[str, Any]:
         return {"config": dict(self.config.__dict__),
                 "components": {"text_variant_generator": self.text_variant_generator is not None,
-                               "retrieval_generator": self.clip_model.engine.bank_rows > 0,
+                               "retrieval_generator": self.clip_model.engine.bank_size(self.bank_name) > 0,
                                "generative_generator": False, "consistency_checker": True}}

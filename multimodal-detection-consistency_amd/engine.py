@@ -69,9 +69,9 @@ class TVCEngine:
         self.arch = arch
         self._lock = threading.Lock()
         self._keep = []          # device tensors / ctypes objects referenced by the handle
-        self._bank = None
-        self.bank_rows = 0
-        self.bank_dim = 0
+        # named bank slots: every owner (retriever index, ReferenceBank, defense references ...) registers
+        # its rows under its own name, so owners sharing one engine cannot replace each other's bank
+        self._banks: Dict[str, Dict] = {}
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             desc = vis = txt = None
@@ -177,9 +177,46 @@ class TVCEngine:
         return out
 
     # ---- bank ----------------------------------------------------------
-    def set_bank(self, bank: torch.Tensor) -> None:
+    DEFAULT_BANK = "default"
+
+    def _slot(self, name: str, create: bool = False) -> Dict:
+        b = self._banks.get(name)
+        if b is None:
+            if not create:
+                raise _lib.TVCError(_lib.TVC_E_STATE, f"no bank registered under the name {name!r}")
+            used = {v["slot"] for v in self._banks.values()}
+            free = [i for i in range(_lib.TVC_MAX_BANKS) if i not in used]
+            if not free:
+                raise _lib.TVCError(_lib.TVC_E_STATE, f"all {_lib.TVC_MAX_BANKS} bank slots of this engine are in use "
+                                                      f"({sorted(self._banks)}); release_bank() one first")
+            b = self._banks[name] = {"slot": free[0], "rows": 0, "dim": 0, "keep": None}
+        return b
+
+    def _select(self, name: str, create: bool = False) -> Dict:
+        """(lock held) point the handle's bank calls at the slot of ``name``."""
+        b = self._slot(name, create)
+        self._check(self.lib.tvc_bank_select(self.handle, b["slot"]))
+        return b
+
+    @property
+    def bank_rows(self) -> int:
+        return self.bank_size(self.DEFAULT_BANK)
+
+    @property
+    def bank_dim(self) -> int:
+        b = self._banks.get(self.DEFAULT_BANK)
+        return b["dim"] if b else 0
+
+    def bank_size(self, name: str = DEFAULT_BANK) -> int:
+        b = self._banks.get(name)
+        return b["rows"] if b else 0
+
+    def has_bank(self, name: str = DEFAULT_BANK) -> bool:
+        return name in self._banks
+
+    def set_bank(self, bank: torch.Tensor, name: str = DEFAULT_BANK) -> None:
         """bank [R, D], rows L2-normalised; bf16 is used in place, fp32 is split
-        into (hi, lo) bf16 planes inside the handle."""
+        into (hi, lo) bf16 planes inside the handle.  ``name`` = the owner's slot."""
         if bank.dim() != 2:
             raise ValueError("bank must be [R, D]")
         if bank.dtype not in (torch.bfloat16, torch.float32):
@@ -187,30 +224,42 @@ class TVCEngine:
         bank = _require_cuda(bank, bank.dtype, "bank")
         dt = _lib.TVC_DTYPE_BF16 if bank.dtype == torch.bfloat16 else _lib.TVC_DTYPE_F32
         with self._lock, torch.cuda.device(self.device):
+            b = self._select(name, create=True)
             self._check(self.lib.tvc_bank_set(self.handle, _ptr(bank), bank.shape[0], bank.shape[1], dt, _stream()))
             if dt == _lib.TVC_DTYPE_F32:
                 torch.cuda.current_stream().synchronize()   # the split read `bank`; it may now be freed
-        self._bank = bank if dt == _lib.TVC_DTYPE_BF16 else None
-        self.bank_rows, self.bank_dim = bank.shape
+            b["keep"] = bank if dt == _lib.TVC_DTYPE_BF16 else None
+            b["rows"], b["dim"] = bank.shape
+
+    def release_bank(self, name: str) -> None:
+        """Forget the bank of ``name`` and free its slot (an fp32 bank's planes are freed too)."""
+        with self._lock, torch.cuda.device(self.device):
+            if name in self._banks:
+                self._select(name)
+                self._check(self.lib.tvc_bank_set(self.handle, None, 0, 64, _lib.TVC_DTYPE_BF16, _stream()))
+                del self._banks[name]
 
     def bank_search(self, rows: torch.Tensor, k: int, count_thr: float = 0.3, idx_offset: int = 0,
-                    want_moments: bool = True):
+                    want_moments: bool = True, bank: str = DEFAULT_BANK):
         """rows fp32 [M, D] -> (idx int32 [M, k], sim fp32 [M, k], moments fp32 [M, 4] | None)."""
+        if not 1 <= k <= _lib.TVC_MAX_TOPK:
+            raise ValueError(f"top-k must be in [1, {_lib.TVC_MAX_TOPK}] (got {k}): tvc_bank_search never truncates silently")
         rows = _require_cuda(rows, torch.float32, "rows")
         M = rows.shape[0]
         idx = torch.empty((M, k), dtype=torch.int32, device=self.device)
         sim = torch.empty((M, k), dtype=torch.float32, device=self.device)
         mom = torch.empty((M, 4), dtype=torch.float32, device=self.device) if want_moments else None
         with self._lock, torch.cuda.device(self.device):
+            self._select(bank)
             self._check(self.lib.tvc_bank_search(self.handle, _ptr(rows), M, k, count_thr, idx_offset,
                                                  _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
         return idx, sim, mom
 
     def bank_search_robust(self, rows: torch.Tensor, k: int, count_thr: float = 0.3, idx_offset: int = 0,
-                           want_moments: bool = True):
+                           want_moments: bool = True, bank: str = DEFAULT_BANK):
         """``bank_search`` + status check; on candidate overflow (degenerate bank) the same
         contract is recomputed by the brute-force kernel.  Synchronises the stream."""
-        out = self.bank_search(rows, k, count_thr, idx_offset, want_moments)
+        out = self.bank_search(rows, k, count_thr, idx_offset, want_moments, bank)
         try:
             self.bank_status()
             return out
@@ -220,8 +269,10 @@ class TVCEngine:
         idx, sim, mom = out
         rows = _require_cuda(rows, torch.float32, "rows")
         with self._lock, torch.cuda.device(self.device):
+            self._select(bank)
             self._check(self.lib.tvc_bank_search_dense(self.handle, _ptr(rows), rows.shape[0], k, count_thr, idx_offset,
                                                        _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
+        self.dense_fallbacks = getattr(self, "dense_fallbacks", 0) + 1
         return idx, sim, mom
 
     def bank_status(self) -> None:
@@ -229,13 +280,14 @@ class TVCEngine:
         with self._lock, torch.cuda.device(self.device):
             self._check(self.lib.tvc_bank_status(self.handle, _stream()))
 
-    def bank_gather(self, idx: torch.Tensor, idx_offset: int = 0) -> torch.Tensor:
+    def bank_gather(self, idx: torch.Tensor, idx_offset: int = 0, bank: str = DEFAULT_BANK) -> torch.Tensor:
         idx = _require_cuda(idx, torch.int32, "idx")
         n = idx.numel()
-        out = torch.empty((n, self.bank_dim), dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
+            b = self._select(bank)
+            out = torch.empty((n, b["dim"]), dtype=torch.float32, device=self.device)
             self._check(self.lib.tvc_bank_gather(self.handle, _ptr(idx), n, idx_offset, _ptr(out), _stream()))
-        return out.view(*idx.shape, self.bank_dim)
+        return out.view(*idx.shape, b["dim"])
 
     def topk_merge(self, idx_parts, sim_parts, feat_parts=None, mom_parts=None):
         """parts [W, M, k] (+ feat [W, M, kf, D], mom [W, M, 4]) -> merged (idx, sim, feat, mom)."""
@@ -282,17 +334,17 @@ class TVCEngine:
         return rec
 
     def detect_embeddings(self, img: torch.Tensor, txt: torch.Tensor, cfg: ConsistencyConfig,
-                          use_bank: bool = True, robust: bool = False) -> torch.Tensor:
+                          use_bank: bool = True, robust: bool = False, bank: str = DEFAULT_BANK) -> torch.Tensor:
         """Bank search of the text rows -> gather -> consistency; all on the current stream.
         ``robust=False``: no host synchronisation, the caller checks ``bank_status()`` later;
         ``robust=True``: synchronises once and falls back to the brute-force search on overflow."""
         B, N1, D = txt.shape
-        if use_bank and self.bank_rows > 0:
+        if use_bank and self.bank_size(bank) > 0:
             k = max(cfg.search_k, cfg.reference_count)
             search = self.bank_search_robust if robust else self.bank_search
-            idx, sim, _ = search(txt.reshape(B * N1, D), k, cfg.similarity_threshold, want_moments=False)
+            idx, sim, _ = search(txt.reshape(B * N1, D), k, cfg.similarity_threshold, want_moments=False, bank=bank)
             kf = cfg.reference_count
-            feat = self.bank_gather(idx[:, :kf].contiguous())
+            feat = self.bank_gather(idx[:, :kf].contiguous(), bank=bank)
             return self.consistency(img, txt, cfg, idx, sim, feat)
         return self.consistency(img, txt, cfg)
 

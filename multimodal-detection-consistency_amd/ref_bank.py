@@ -63,10 +63,17 @@ class ReferenceBank:
         self._lock = Lock()
         self._dirty = True
         self._rng = rng or np.random.default_rng()
+        self.bank_name = f"ref_bank:{id(self):x}"       # own bank slot on the (possibly shared) engine
         self.stats = {"total_added": 0, "total_removed": 0, "total_queries": 0}
 
     def __len__(self) -> int:
         return len(self.references)
+
+    def __del__(self):          # give the bank slot back to the (possibly shared) engine
+        try:
+            self.engine.release_bank(self.bank_name)
+        except Exception:
+            pass
 
     # -- device copy ----------------------------------------------------------
     def _padded_dim(self) -> int:
@@ -81,7 +88,7 @@ class ReferenceBank:
             V[i, :D] = r.vector
         n = np.linalg.norm(V, axis=1, keepdims=True)
         V = V / np.where(n == 0, 1.0, n)          # cosine = dot of unit rows; the +1e-8 of :482 is < 1e-9 here
-        self.engine.set_bank(torch.from_numpy(V.astype(np.float32)).to(self.engine.device))
+        self.engine.set_bank(torch.from_numpy(V.astype(np.float32)).to(self.engine.device), name=self.bank_name)
         self._dirty = False
 
     def _query_rows(self, q: np.ndarray) -> torch.Tensor:
@@ -111,7 +118,7 @@ class ReferenceBank:
         if not self.references:
             return False
         self._sync_device()
-        _, sim, _ = self.engine.bank_search_robust(self._query_rows(vector), 1, want_moments=False)
+        _, sim, _ = self.engine.bank_search_robust(self._query_rows(vector), 1, want_moments=False, bank=self.bank_name)
         return bool(sim[0, 0].item() > self.config.similarity_threshold)
 
     def add_reference(self, vector: np.ndarray, metadata: Dict[str, Any]) -> bool:
@@ -159,8 +166,11 @@ class ReferenceBank:
                 return []
             thr = similarity_threshold or self.config.similarity_threshold       # :191 (0.0 falls through)
             self._sync_device()
-            k = max(1, min(top_k, 32))
-            idx, sim, _ = self.engine.bank_search_robust(self._query_rows(query_vector), k, thr, want_moments=False)
+            # the reference accepts any top_k (src/ref_bank.py:172,203); more than the bank holds cannot come
+            # back, and beyond the kernel's TVC_MAX_TOPK the engine raises -- never a silent truncation
+            k = max(1, min(top_k, len(self.references)))
+            idx, sim, _ = self.engine.bank_search_robust(self._query_rows(query_vector), k, thr, want_moments=False,
+                                                         bank=self.bank_name)
             idx, sim = idx[0].cpu().numpy(), sim[0].cpu().numpy().astype(np.float64)
             out = []
             for i, s in zip(idx, sim):

@@ -50,11 +50,18 @@ class MultiModalRetriever:
         self.texts: List[str] = []
         self.retrieval_cache: Dict[str, Tuple[List[str], List[float]]] = {}
         self._bank_is = None        # "image" / "text": which index lives on the engine
+        self.bank_name = f"retriever:{id(self):x}"      # this retriever's own bank slot on the (shared) engine
+
+    def __del__(self):          # give the bank slot back to the shared engine
+        try:
+            self.clip_model.engine.release_bank(self.bank_name)
+        except Exception:
+            pass
 
     # -- index construction (src/retrieval.py:372-432, scripts/build_faiss_indices.py:59-158)
     def _set_bank(self, feats: torch.Tensor, kind: str) -> None:
         dt = torch.bfloat16 if self.config.bank_dtype == "bfloat16" else torch.float32
-        self.clip_model.engine.set_bank(feats.to(self.clip_model.device, dt))
+        self.clip_model.engine.set_bank(feats.to(self.clip_model.device, dt), name=self.bank_name)
         self._bank_is = kind
 
     def build_image_index(self, images: Union[Sequence[str], torch.Tensor], batch_size: Optional[int] = None) -> np.ndarray:
@@ -95,7 +102,9 @@ class MultiModalRetriever:
     # -- queries (src/retrieval.py:527-680) ----------------------------------
     def _search(self, q: torch.Tensor, top_k: int) -> Tuple[np.ndarray, np.ndarray]:
         eng = self.clip_model.engine
-        idx, sim, _ = eng.bank_search_robust(q, min(top_k, 32), want_moments=False)
+        # the reference accepts any top_k (src/retrieval.py:636); the kernel's limit is TVC_MAX_TOPK and the
+        # engine raises beyond it -- never a silent truncation.  More than R rows cannot be returned (-1 padded).
+        idx, sim, _ = eng.bank_search_robust(q, top_k, want_moments=False, bank=self.bank_name)
         idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
         return idx, sim
 
@@ -178,6 +187,7 @@ class RetrievalReferenceGenerator:
         self.reference_features = None
         self.reference_metadata: list = []
         self.feature_cache: Dict[int, List[Dict[str, Any]]] = {}
+        self.bank_name = f"retrieval_ref:{id(self):x}"  # own bank slot on the (shared) engine
         self.retrieval_stats = {"total_queries": 0, "successful_retrievals": 0, "cache_hits": 0}
         if features is not None:
             self._register(torch.as_tensor(features), metadata or [])
@@ -189,22 +199,29 @@ class RetrievalReferenceGenerator:
                     meta = json.load(f)
                 self._register(torch.from_numpy(feats), meta)
 
+    def __del__(self):
+        try:
+            self.clip_model.engine.release_bank(self.bank_name)
+        except Exception:
+            pass
+
     def _register(self, feats: torch.Tensor, meta: list) -> None:
         self.reference_features = feats
         self.reference_metadata = meta
         self.clip_model.engine.set_bank(feats.float().to(self.clip_model.device) if feats.dtype != torch.bfloat16
-                                        else feats.to(self.clip_model.device))
+                                        else feats.to(self.clip_model.device), name=self.bank_name)
 
     def retrieve_references_batch(self, texts: Sequence[str]) -> List[List[Dict[str, Any]]]:
         eng = self.clip_model.engine
-        if self.reference_features is None or eng.bank_rows == 0:
+        rows = eng.bank_size(self.bank_name)
+        if self.reference_features is None or rows == 0:
             return [[] for _ in texts]                                     # retrieval_ref.py:195-197
         c = self.config
         q = self.clip_model.encode_tokens(self.clip_model.tokenize(list(texts)), True)    # :238-244
-        search_k = min(c.rerank_top_k if c.enable_reranking else c.reference_count, eng.bank_rows, 32)   # :249
-        idx, sim, _ = eng.bank_search_robust(q, search_k, c.similarity_threshold, want_moments=False)
+        search_k = min(c.rerank_top_k if c.enable_reranking else c.reference_count, rows)   # :249
+        idx, sim, _ = eng.bank_search_robust(q, search_k, c.similarity_threshold, want_moments=False, bank=self.bank_name)
         keep = min(c.reference_count, search_k)
-        feats = eng.bank_gather(idx[:, :keep].contiguous()).cpu().numpy()
+        feats = eng.bank_gather(idx[:, :keep].contiguous(), bank=self.bank_name).cpu().numpy()
         idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
         out = []
         for r in range(len(texts)):

@@ -62,7 +62,11 @@ class HipShardOps:
         self.count_thr = count_thr
 
     def search(self, rows: torch.Tensor, k: int):
-        idx, sim, _ = self.engine.bank_search(rows, k, self.count_thr, idx_offset=self.row_offset, want_moments=False)
+        # the status-checked form: a candidate-list overflow on THIS shard (clustered / duplicate-heavy
+        # rows) would otherwise drop true top-k rows of every rank's queries with nothing to show for it
+        # after the merge.  The brute-force fallback is local to the shard, so it is safe collectively.
+        idx, sim, _ = self.engine.bank_search_robust(rows, k, self.count_thr, idx_offset=self.row_offset,
+                                                     want_moments=False)
         return idx, sim
 
     def gather(self, idx: torch.Tensor):

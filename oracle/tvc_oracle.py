@@ -136,23 +136,34 @@ def detect_adversarial_src(image_feat: np.ndarray,
                            methods: Sequence[str] = ('text_variants', 'consistency'),
                            sd_ref_feats: Optional[np.ndarray] = None,
                            detection_threshold: float = 0.5,
-                           score_aggregation: str = 'weighted_mean') -> Dict:
+                           score_aggregation: str = 'weighted_mean',
+                           has_text_augmenter: bool = True,
+                           has_sd_generator: Optional[bool] = None) -> Dict:
     """src/detector.py:345-410 (``detect_adversarial``) on embeddings.
 
     ``text_feats`` is ``[N+1, D]``: row 0 the original text, rows 1.. the
     variants (src/detector.py:461-471).  ``sd_ref_feats`` (``[J, D]``) stands
     for the encoded SD reference images (src/detector.py:528-534); producing
     them is out of scope.
+
+    A method is scored whenever it is requested AND its component exists
+    (``self._get_text_augmenter() is not None`` :375, ``self._get_sd_generator() is not None``
+    :382).  A component that exists but yields nothing (no variants :457-458, no images
+    :524-525) still contributes its 0.0 score to the aggregation: with the default weights
+    ``aggregated = (0.4 * 0 + 0.2 * cs) / 0.6``.  ``has_sd_generator`` defaults to
+    "``sd_ref_feats`` was given".
     """
     text_feats = np.asarray(text_feats)
     s0 = cosine(image_feat, text_feats[0])
     scores, details = {}, {}
-    if 'text_variants' in methods and text_feats.shape[0] > 1:
+    if has_sd_generator is None:
+        has_sd_generator = sd_ref_feats is not None
+    if 'text_variants' in methods and has_text_augmenter:
         sv = [cosine(image_feat, t) for t in text_feats[1:]]
-        scores['text_variants'], details['text_variants'] = text_variant_score(s0, sv)
-    if 'sd_reference' in methods and sd_ref_feats is not None and len(sd_ref_feats):
-        sims = [cosine(image_feat, r) for r in sd_ref_feats]
-        scores['sd_reference'], details['sd_reference'] = sd_reference_score(sims)
+        scores['text_variants'], details['text_variants'] = text_variant_score(s0, sv)   # 0.0 + error when empty
+    if 'sd_reference' in methods and has_sd_generator:
+        sims = [cosine(image_feat, r) for r in sd_ref_feats] if sd_ref_feats is not None else []
+        scores['sd_reference'], details['sd_reference'] = sd_reference_score(sims)       # 0.0 + error when empty
     if 'consistency' in methods:
         scores['consistency'], details['consistency'] = consistency_score(s0)
     agg = aggregate_scores(scores, score_aggregation)
@@ -416,7 +427,8 @@ def detect_batch(image_feats: np.ndarray, text_feats: np.ndarray,
                  retrieval_top_k: int = 10,
                  detection_threshold: float = 0.5,
                  checker: Optional[ConsistencyCheckerOracle] = None,
-                 src_methods: Sequence[str] = ('text_variants', 'consistency')) -> Dict[str, np.ndarray]:
+                 src_methods: Sequence[str] = ('text_variants', 'consistency'),
+                 has_text_augmenter: bool = True) -> Dict[str, np.ndarray]:
     """Run both polarities for every query, in input order (the order matters
     for the stateful checker, consistency_checker.py:105,235).
 
@@ -435,7 +447,7 @@ def detect_batch(image_feats: np.ndarray, text_feats: np.ndarray,
     out['retrieval_indices'] = np.full((B, retrieval_top_k), -1, np.int64)
     for b in range(B):
         r = detect_adversarial_src(image_feats[b], text_feats[b], methods=src_methods,
-                                   detection_threshold=detection_threshold)
+                                   detection_threshold=detection_threshold, has_text_augmenter=has_text_augmenter)
         out['score_src'][b] = r['aggregated_score']
         out['is_adv_src'][b] = r['is_adversarial']
         refs_idx: List[int] = []

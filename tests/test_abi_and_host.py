@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(pkg._lib.SIGNATURES), declared ^ set(pkg._lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in tvc.h but not exported"
-    assert lib.tvc_abi_version() == 1
+    assert lib.tvc_abi_version() == pkg._lib.TVC_ABI_VERSION == 2
     out = subprocess.run(["nm", "-D", "--defined-only", str(pkg._lib.LIB_PATH)], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (tvc_[a-z0-9_]+)", out))
     assert declared <= exported
@@ -143,3 +143,67 @@ def test_shard_bounds(pkg):
         assert spans[0][0] == 0 and spans[-1][1] == R
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert all(hi >= lo for lo, hi in spans)
+
+
+def test_bench_gpus_flag_launches_ranks_dry_run():
+    """`python bench.py --gpus N` (no torchrun environment) must start N ranks itself and print ONE line with
+    n_gpus = N (replaces src/utils/multi_gpu_processor.py:494-620 at the driver's entry point).  Dry run:
+    gloo group, barrier, max-over-ranks reduction, no GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run-launch", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["max_over_ranks_s"] == pytest.approx(2e-3)
+
+
+def test_oracle_empty_component_semantics():
+    """src/detector.py:375-383,457-458,524-525: a requested method whose component exists but yields nothing still
+    contributes its 0.0 score; it is omitted only when the component is absent."""
+    from oracle import tvc_oracle as O
+    rng = np.random.default_rng(0)
+    img, txt = rng.standard_normal(64), rng.standard_normal((1, 64))
+    cs = 1.0 - O.cosine(img, txt[0])
+    r = O.detect_adversarial_src(img, txt)                                           # augmenter present, no variants
+    assert r["detection_scores"]["text_variants"] == 0.0 and "error" in r["detection_details"]["text_variants"]
+    assert r["aggregated_score"] == pytest.approx((0.4 * 0.0 + 0.2 * cs) / 0.6)
+    r = O.detect_adversarial_src(img, txt, has_text_augmenter=False)                  # no augmenter: omitted
+    assert "text_variants" not in r["detection_scores"] and r["aggregated_score"] == pytest.approx(cs)
+    r = O.detect_adversarial_src(img, txt, methods=("text_variants", "sd_reference", "consistency"),
+                                 sd_ref_feats=np.zeros((0, 64)))                      # generator present, no images
+    assert r["detection_scores"]["sd_reference"] == 0.0
+    assert r["aggregated_score"] == pytest.approx(0.2 * cs / 1.0)
+    r = O.detect_adversarial_src(img, txt, methods=("text_variants", "sd_reference", "consistency"))
+    assert "sd_reference" not in r["detection_scores"]                                 # no generator: omitted
+
+
+def test_pgd_fixture_matches_the_oracle(pkg):
+    """The committed Q = 1000 PGD fixture is self-consistent: images rebuilt from the packed sign bits, the
+    fp32 CPU oracle towers and the reference arithmetic reproduce the stored embeddings / scores for a few
+    clean and adversarial queries (the GPU test then only needs the stored oracle outputs)."""
+    import torch
+    from oracle import clip_oracle, make_pgd_fixture as F, tvc_oracle as O
+    fx = F.load_fixture(pkg)
+    arch, (vw, tw) = fx["arch"], fx["weights"]
+    assert fx["images"].shape == (F.Q, 3, 224, 224) and fx["labels"].sum() == F.Q // 2
+    adv = fx["images"][F.Q // 2:]
+    assert adv.min().item() >= 0.0 and adv.max().item() <= 1.0                       # clamp of the NORMALISED tensor
+    pick = [0, 1, 500, 501]
+    pos = [int(np.where(fx["oracle"]["feat_sample"] == q)[0][0]) for q in pick]
+    with torch.no_grad():
+        fi = clip_oracle.vision_forward(vw, fx["images"][pick], arch.vision.heads, arch.patch)
+        ft = clip_oracle.text_forward(tw, fx["tokens"][pick].reshape(-1, arch.ctx).long(), arch.text.heads).view(4, F.N + 1, -1)
+    o = fx["oracle"]
+    assert (fi - torch.from_numpy(o["image_feats"][pos])).abs().max().item() < 2e-5
+    assert (ft - torch.from_numpy(o["text_feats"][pos])).abs().max().item() < 2e-5
+    ref = O.detect_batch(fi.numpy(), ft.numpy(), fx["bank"].float().numpy(),
+                         checker=O.ConsistencyCheckerOracle(adaptive_threshold=False))
+    assert np.abs(ref["score_src"] - o["score_src"][pick]).max() < 1e-5
+    assert np.abs(ref["overall_exp"] - o["overall_exp"][pick]).max() < 1e-5
+    assert abs(O.detection_metrics(o["score_src"], fx["labels"])["auc"] - float(o["auc_src"])) < 1e-12

@@ -206,3 +206,93 @@ def test_topk_merge_kernel(gpu_engine):
             w, j = divmod(int(order[m, r]), k)
             assert torch.equal(of[m, r].cpu(), feat[w, m, j])
     assert torch.allclose(om[:, 0].cpu(), mom[:, :, 0].sum(0)) and torch.allclose(om[:, 2].cpu(), mom[:, :, 2].max(0).values)
+
+
+def test_empty_components_follow_the_reference(pkg, clip, images):
+    """src/detector.py:375-383,457-458,524-525: augmenter / generator present but empty -> the method's 0.0
+    score still enters the weighted mean (aggregated = cs / 3 with the default weights), on the host result
+    AND in the device record; component absent -> method omitted."""
+    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=4), clip_model=clip)
+    fi = clip.encode_image(images).cpu().numpy()
+    refs = [pkg.synth.make_images(3, 64, seed=60), pkg.synth.make_images(2, 64, seed=61)]
+    res = det.batch_detect(images[:3], TEXTS[:3], variants=[[], [], []],
+                           reference_images=[[], list(refs[0]), list(refs[1])])
+    for i in range(3):
+        ft = clip.encode_text([TEXTS[i]]).numpy()
+        fr = clip.encode_image(refs[i - 1].cuda()).cpu().numpy() if i else np.zeros((0, fi.shape[1]))
+        want = O.detect_adversarial_src(fi[i], ft, methods=("text_variants", "sd_reference", "consistency"), sd_ref_feats=fr)
+        got = res[i]
+        assert set(got["detection_scores"]) == {"text_variants", "sd_reference", "consistency"}
+        assert got["detection_scores"]["text_variants"] == 0.0 and "error" in got["detection_details"]["text_variants"]
+        for m in ("sd_reference", "consistency"):
+            assert abs(got["detection_scores"][m] - want["detection_scores"][m]) < 1e-4
+        assert abs(got["aggregated_score"] - want["aggregated_score"]) < 1e-4
+        assert got["is_adversarial"] == want["is_adversarial"]
+    assert "error" in res[0]["detection_details"]["sd_reference"] and res[1]["detection_details"]["sd_reference"]["num_references"] == 3
+    # device record word 5 with N = 0
+    tok = clip.tokenize(TEXTS[:3]).view(3, 1, -1)
+    rec = det.detect_tokens(images[:3], tok)
+    for i in range(3):
+        want = O.detect_adversarial_src(fi[i], clip.encode_text([TEXTS[i]]).numpy())
+        assert abs(rec["aggregated_score"][i] - want["aggregated_score"]) < 1e-4
+    # component absent: omitted, aggregated = consistency score
+    det2 = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-T/16-test", use_text_variants=False), clip_model=clip)
+    r2 = det2.batch_detect(images[:2], TEXTS[:2])
+    for i in range(2):
+        assert set(r2[i]["detection_scores"]) == {"consistency"}
+        want = O.detect_adversarial_src(fi[i], clip.encode_text([TEXTS[i]]).numpy(), has_text_augmenter=False)
+        assert abs(r2[i]["aggregated_score"] - want["aggregated_score"]) < 1e-4
+    assert abs(det2.detect_tokens(images[:2], tok[:2])["aggregated_score"][0] - r2[0]["aggregated_score"]) < 1e-6
+
+
+def test_bank_owners_do_not_clobber_each_other(pkg, clip, images):
+    """One CLIPModel / engine shared by a pipeline retriever (image index), a MultiModalDefenseDetector
+    (reference features), a RetrievalReferenceGenerator and a ReferenceBank: each keeps ITS rows
+    (src/pipeline.py:306-331 builds them on one model; here every owner has a named slot, tvc_bank_select)."""
+    pipe = pkg.create_detection_pipeline(
+        pkg.PipelineConfig(enable_sd_reference=False,
+                           detector_config=pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=2)),
+        clip_model=clip)
+    pipe.retriever.build_image_index(pkg.synth.make_images(40, 64, seed=9))
+    before = pipe.retriever.retrieve_images_by_text(TEXTS[0], top_k=5)
+    det = pkg.MultiModalDefenseDetector(clip, config=pkg.DetectionConfig(text_variant_count=2))
+    ft = clip.encode_text(TEXTS)
+    bank = pkg.synth.plant_neighbours(pkg.synth.make_bank(3000, 128, seed=7), ft, per_anchor=2).to(torch.bfloat16)
+    det.set_reference_bank(bank)
+    d1 = det.batch_detect(images, TEXTS, return_details=True)
+    gen = pkg.RetrievalReferenceGenerator(clip, features=pkg.synth.make_bank(500, 128, seed=8).numpy(),
+                                          metadata=[{"i": i} for i in range(500)])
+    rb = pkg.ReferenceBank(pkg.ReferenceBankConfig(feature_dim=128, similarity_threshold=0.0), engine=clip.engine)
+    rb.add_references(np.random.default_rng(0).standard_normal((30, 128)))
+    assert len(rb.query_similar(np.random.default_rng(1).standard_normal(128), top_k=40, similarity_threshold=-1.0)) == 30
+    gen.retrieve_references(TEXTS[1])
+    # every owner still sees its own rows
+    pipe.retriever.retrieval_cache.clear()
+    assert pipe.retriever.retrieve_images_by_text(TEXTS[0], top_k=5) == before
+    det.consistency_checker.reset()
+    d2 = det.batch_detect(images, TEXTS, return_details=True)
+    assert [x["details"]["retrieval_references"] for x in d1] == [x["details"]["retrieval_references"] for x in d2]
+    assert any(x["details"]["retrieval_references"] for x in d1)
+    assert len({pipe.retriever.bank_name, det.bank_name, gen.bank_name, rb.bank_name}) == 4
+    with pytest.raises(ValueError):
+        pipe.retriever.retrieve_images_by_text(TEXTS[0], top_k=200)       # > TVC_MAX_TOPK: raises, never truncates
+
+
+def test_bench_gpus_flag_runs_two_ranks_on_one_gpu(pkg):
+    """`python bench.py --gpus 2` starts two worker ranks itself; on the one-GPU box they time-share cuda:0 over
+    gloo (--rehearse-one-gpu).  Both layouts: data-parallel and --shard-bank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--model", "ViT-T/16-test",
+            "--batch", "16", "--variants", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    for extra in (["--bank-rows", "4096"], ["--bank-rows", "8192", "--shard-bank"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 32

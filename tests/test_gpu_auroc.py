@@ -39,3 +39,54 @@ def test_auroc_matches_cpu_oracle(pkg):
     # scores themselves: bf16 towers vs fp32 towers
     assert np.abs(got - ref).max() < 2e-2
     clip.engine.close()
+
+
+def test_auroc_q1000_vit_b32_committed_pgd_fixture(pkg):
+    """Q = 1000 (500 clean + 500 PGD) at ViT-B/32, N = 4, 1k-row planted bank, on the
+    COMMITTED fixture (tests/golden/pgd_b32_q1000.npz, generated once in the build container by
+    oracle/make_pgd_fixture.py through oracle/synth_pgd.py = /root/reference/src/attacks/pgd_attack.py:406-523).
+    The fixture also carries the CPU oracle's scores (fp32 towers + reference arithmetic), so both sides saw
+    identical inputs.  Bar: |dAUROC| <= 0.002 in BOTH polarities (src: high = adversarial,
+    src/detector.py:399; exp: low = adversarial, consistency_checker.py:93; AUROC =
+    sklearn.roc_auc_score, src/utils/metrics.py:300)."""
+    from oracle import make_pgd_fixture as F
+    fx = F.load_fixture(pkg)
+    arch, (vw, tw) = fx["arch"], fx["weights"]
+    Q, N = F.Q, F.N
+    eng = pkg.TVCEngine(arch, vw, tw)
+    eng.set_bank(fx["bank"].cuda())
+    cfg = pkg.ConsistencyConfig()
+    recs, fis, fts = [], [], []
+    for i in range(0, Q, 250):
+        fi = eng.encode_image(fx["images"][i:i + 250].cuda())
+        ft = eng.encode_text(fx["tokens"][i:i + 250].reshape(-1, arch.ctx).cuda(), group=N + 1).view(-1, N + 1, arch.embed_dim)
+        recs.append(eng.detect_embeddings(fi, ft, cfg, robust=True).cpu().numpy())
+        fis.append(fi.cpu()); fts.append(ft.cpu())
+    rec = np.concatenate(recs)
+    o, labels = fx["oracle"], fx["labels"]
+    auc_src = tvc_oracle.detection_metrics(rec[:, 5], labels)["auc"]
+    auc_exp = tvc_oracle.detection_metrics(-rec[:, 10].astype(np.float64), labels)["auc"]
+    d_src = np.abs(rec[:, 5] - o["score_src"])
+    d_exp = np.abs(rec[:, 10] - o["overall_exp"])
+    d_s0 = np.abs(rec[:, 0] - o["original_similarity"])
+    # embeddings on the 128-query sample the fixture keeps
+    S = o["feat_sample"]
+    fi, ft = torch.cat(fis)[S], torch.cat(fts)[S]
+    cos_i = (fi * torch.from_numpy(o["image_feats"])).sum(-1)
+    cos_t = (ft * torch.from_numpy(o["text_feats"])).sum(-1)
+    print(f"[measured] ViT-B/32 Q=1000: AUROC src oracle {float(o['auc_src']):.4f} gpu {auc_src:.4f}; "
+          f"exp oracle {float(o['auc_exp']):.4f} gpu {auc_exp:.4f}")
+    print(f"[measured] ViT-B/32 Q=1000 |score_gpu - score_cpu_fp32|: score_src max {d_src.max():.2e} p99 {np.percentile(d_src, 99):.2e} "
+          f"median {np.median(d_src):.2e}; overall_exp max {d_exp.max():.2e} p99 {np.percentile(d_exp, 99):.2e}; "
+          f"original_similarity max {d_s0.max():.2e}; image min cos {cos_i.min().item():.6f} max|d| "
+          f"{(fi - torch.from_numpy(o['image_feats'])).abs().max().item():.2e}; text min cos {cos_t.min().item():.6f} "
+          f"max|d| {(ft - torch.from_numpy(o['text_feats'])).abs().max().item():.2e}")
+    assert abs(auc_src - float(o["auc_src"])) <= 0.002
+    assert abs(auc_exp - float(o["auc_exp"])) <= 0.002
+    # the published end-to-end figure (DESIGN.md section 2): bf16 towers vs fp32 CPU towers, ViT-B/32
+    assert d_src.max() < 5e-3 and d_s0.max() < 5e-3
+    assert cos_i.min().item() > 0.999 and cos_t.min().item() > 0.999
+    # decisions: identical except where the score sits within the measured deviation of the threshold
+    flip = (rec[:, 5] > 0.5) != o["is_adv_src"]
+    assert (np.abs(o["score_src"][flip] - 0.5) < 5e-3).all()
+    eng.close()

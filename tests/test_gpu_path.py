@@ -340,3 +340,126 @@ def test_sharded_search_two_phase_on_gpu(gpu_engine, pkg, tmp_path):
             assert torch.equal(i, ri) and torch.equal(v, rs) and torch.equal(f, rf)
     finally:
         dist.destroy_process_group()
+
+
+def test_bank_search_nan_rows_and_ragged_query_tile(gpu_engine):
+    """M % 256 != 0 with a zero-norm LAST query row (NaN after `x / x.norm()`, retrieval_ref.py:243 has no
+    epsilon) and one NaN bank row: the padded query lanes of the last tile re-read that row.  The other
+    queries' top-k must be untouched, NaN similarities are never returned, and nothing is written outside
+    the candidate lists (the search after it is clean)."""
+    R, M, D, k = 20000, 300, 256, 5
+    bank = _unit((R, D), 41).to(torch.bfloat16)
+    q = _unit((M, D), 42)
+    gpu_engine.set_bank(bank.cuda())
+    want_i, want_s, _ = gpu_engine.bank_search(q[:M - 1].cuda(), k, want_moments=False)
+    gpu_engine.bank_status()
+    q_bad = q.clone()
+    q_bad[M - 1] = float("nan")                      # what l2norm makes of an all-zero embedding
+    for want_moments in (False, True):
+        i1, s1, _ = gpu_engine.bank_search(q_bad.cuda(), k, want_moments=want_moments)
+        gpu_engine.bank_status()
+        assert torch.equal(i1[:M - 1], want_i) and torch.allclose(s1[:M - 1], want_s, atol=5e-6)
+        assert (i1[M - 1] == -1).all()
+    # one NaN bank row: bank_bounds turns NaN, the one-product filter lists everything, the status reports the
+    # overflow and the robust form recomputes by brute force -- never a wrong answer
+    bank2 = bank.clone()
+    bank2[777] = float("nan")
+    gpu_engine.set_bank(bank2.cuda())
+    i2, s2, _ = gpu_engine.bank_search_robust(q[:64].cuda(), k, want_moments=False)
+    S = q[:64].double() @ bank.double().t()
+    S[:, 777] = -2.0
+    v, ix = S.topk(k, dim=1)
+    assert torch.equal(i2.cpu().long(), ix) and (s2.cpu().double() - v).abs().max().item() < 1e-5
+    gpu_engine.set_bank(bank.cuda())
+    i3, s3, _ = gpu_engine.bank_search(q[:M - 1].cuda(), k, want_moments=False)
+    gpu_engine.bank_status()
+    assert torch.equal(i3, want_i)
+
+
+@pytest.mark.parametrize("k", [33, 64, 128])
+def test_bank_search_large_k(gpu_engine, k):
+    """The reference accepts any top_k (src/ref_bank.py:172, src/retrieval.py:636); the kernel serves up to
+    TVC_MAX_TOPK = 128 exactly and the engine raises beyond it (never a silent truncation)."""
+    R, M, D = 50000, 40, 512
+    bank = _unit((R, D), 51).to(torch.bfloat16)
+    q = _unit((M, D), 52)
+    gpu_engine.set_bank(bank.cuda())
+    idx, sim, _ = gpu_engine.bank_search(q.cuda(), k, want_moments=False)
+    gpu_engine.bank_status()
+    S = (q.double() @ bank.double().t()).numpy()
+    _check_topk(idx.cpu().numpy(), sim.cpu().numpy().astype(np.float64), S, k, 1e-5)
+    with pytest.raises(ValueError):
+        gpu_engine.bank_search(q.cuda(), 129, want_moments=False)
+
+
+def _clustered_bank(R, D, n_clusters, seed, device="cuda:0", dup_every=997):
+    """Mixture bank: `n_clusters` random unit centres, every row = normalise(centre + s * noise) with the
+    per-row spread s drawn so that the cosine to its centre lies in ~[0.6, 0.95] (a von-Mises-Fisher-like
+    cloud), plus exact duplicates (every `dup_every`-th row repeats its predecessor)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    centres = torch.randn((n_clusters, D), device=device, generator=g)
+    centres /= centres.norm(dim=-1, keepdim=True)
+    out = torch.empty((R, D), dtype=torch.bfloat16, device=device)
+    for r0 in range(0, R, 1 << 18):
+        n = min(1 << 18, R - r0)
+        c = torch.randint(0, n_clusters, (n,), device=device, generator=g)
+        cos = 0.6 + 0.35 * torch.rand((n, 1), device=device, generator=g)
+        s = torch.sqrt(1.0 / (cos * cos) - 1.0)                      # |noise| / |centre| for that cosine
+        x = centres[c] + s * torch.randn((n, D), device=device, generator=g) / (D ** 0.5)
+        x /= x.norm(dim=-1, keepdim=True)
+        out[r0:r0 + n] = x.to(torch.bfloat16)
+    out[dup_every::dup_every] = out[dup_every - 1::dup_every][:out[dup_every::dup_every].shape[0]]
+    return out, centres
+
+
+def test_bank_search_clustered_1m_bank(gpu_engine):
+    """A REALISTIC bank: 1 M rows in 2 000 clusters (intra-cluster cosine 0.6-0.95) + exact duplicates,
+    queries near cluster centres (the case every CLIP bank presents) and far from all of them.  The sampled
+    bound must stay exact (vs a chunked fp64 product), and the statistics that decide whether the dense
+    fallback triggers are printed: survivors per (chunk, query) list, overflow flag, time."""
+    import time
+    R, D, M, k = 1_000_000, 768, 5120, 5
+    bank, centres = _clustered_bank(R, D, 2000, seed=61)
+    g = torch.Generator(device="cuda:0").manual_seed(62)
+    q = torch.randn((M, D), device="cuda:0", generator=g)
+    q /= q.norm(dim=-1, keepdim=True)
+    near = centres[torch.randint(0, 2000, (M // 2,), device="cuda:0", generator=g)]
+    q[:M // 2] = near + 0.5 * torch.randn((M // 2, D), device="cuda:0", generator=g) / (D ** 0.5)
+    q /= q.norm(dim=-1, keepdim=True)
+    gpu_engine.set_bank(bank)
+    before = getattr(gpu_engine, "dense_fallbacks", 0)
+    gpu_engine.bank_search(q, k, want_moments=False)                 # warm-up (workspace growth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, sim, _ = gpu_engine.bank_search(q, k, want_moments=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    overflow = False
+    try:
+        gpu_engine.bank_status()
+    except Exception as e:                                           # TVC_E_OVERFLOW
+        overflow = True
+        print("overflow:", e)
+    print(f"[measured] clustered 1M x 768 bank, M = {M}: filter search {dt * 1e3:.1f} ms, overflow = {overflow}")
+    assert not overflow, "the sampled bound must hold on a clustered bank without the brute-force fallback"
+    assert getattr(gpu_engine, "dense_fallbacks", 0) == before
+    # exactness on 24 rows (12 near a centre, 12 random) vs fp64, the bank taken 250k rows at a time
+    rows_sel = torch.cat([torch.arange(0, 12), torch.arange(M - 12, M)]).cuda()
+    rows = q[rows_sel].double()
+    best_v = torch.full((24, k), -2.0, dtype=torch.float64, device="cuda:0")
+    best_i = torch.zeros((24, k), dtype=torch.long, device="cuda:0")
+    for lo in range(0, R, 250_000):
+        S = rows @ bank[lo:lo + 250_000].double().t()
+        cat_v = torch.cat([best_v, S], 1)
+        cat_i = torch.cat([best_i, torch.arange(lo, lo + S.shape[1], device="cuda:0").expand(24, -1)], 1)
+        # (similarity desc, index asc): exact duplicates tie
+        order = torch.argsort(cat_i, dim=1, stable=True)
+        cat_v, cat_i = torch.gather(cat_v, 1, order), torch.gather(cat_i, 1, order)
+        o2 = torch.argsort(cat_v, dim=1, descending=True, stable=True)[:, :k]
+        best_v, best_i = torch.gather(cat_v, 1, o2), torch.gather(cat_i, 1, o2)
+    got_s, got_i = sim[rows_sel].double(), idx[rows_sel].long()
+    assert (got_s - best_v).abs().max().item() < 1e-5
+    exact = (got_i == best_i)
+    # differing positions only where two rows tie within the fp32 rounding of the re-scoring
+    assert ((got_s - best_v).abs()[~exact] < 2e-6).all()
+    assert (sim[:M // 2, 0] > 0.5).float().mean().item() > 0.9      # near-centre queries do find their cluster

@@ -84,9 +84,12 @@ def test_auroc_q1000_vit_b32_committed_pgd_fixture(pkg):
     assert abs(auc_src - float(o["auc_src"])) <= 0.002
     assert abs(auc_exp - float(o["auc_exp"])) <= 0.002
     # the published end-to-end figure: bf16 towers vs fp32 CPU towers, ViT-B/32
-    assert d_src.max() < 5e-3 and d_s0.max() < 5e-3
-    assert cos_i.min().item() > 0.999 and cos_t.min().item() > 0.999
+    # measured on MI355X: score_src max 7.5e-4 (p99 6.0e-4), original_similarity max 1.4e-3; the exp-polarity
+    # overall score is DISCONTINUOUS where a component cosine crosses 0 (consistency_checker.py:152 keeps scores > 0
+    # only), so its worst case (1.3e-2, p99 3.6e-3) is set by sign flips of near-zero cosines, not by rounding
+    assert d_src.max() < 1.5e-3 and d_s0.max() < 3e-3 and np.percentile(d_exp, 99) < 8e-3
+    assert cos_i.min().item() > 0.99998 and cos_t.min().item() > 0.9999         # measured 0.999993 / 0.999964
     # decisions: identical except where the score sits within the measured deviation of the threshold
     flip = (rec[:, 5] > 0.5) != o["is_adv_src"]
-    assert (np.abs(o["score_src"][flip] - 0.5) < 5e-3).all()
+    assert (np.abs(o["score_src"][flip] - 0.5) < 1.5e-3).all()
     eng.close()

@@ -25,11 +25,11 @@ pytestmark = pytest.mark.gpu
 
 # asserted bounds = ~2x the deviations measured on MI355X (DESIGN.md section 2, table "measured deviation")
 TOWER_BOUNDS = {          # (min cos, max |d embedding|) vs bf16-rounded weights / vs fp32 weights
-    "image": {"bf16w": (0.9990, 4.0e-3), "fp32w": (0.9990, 4.0e-3)},
-    "text": {"bf16w": (0.9990, 4.0e-3), "fp32w": (0.9990, 4.0e-3)},
+    "image": {"bf16w": (0.99999, 7e-4), "fp32w": (0.99998, 1e-3)},      # measured 0.999997 / 3.2e-4, 0.999994 / 4.6e-4
+    "text": {"bf16w": (0.99996, 1.5e-3), "fp32w": (0.99994, 2.2e-3)},     # measured 0.999985 / 6.9e-4, 0.999973 / 1.0e-3
 }
-SCORE_BOUND_SAME_EMB = 1e-4      # BASELINE.json bar, identical embeddings
-SCORE_BOUND_END_TO_END = 5e-3    # bf16 towers vs fp32 CPU towers, score_src / original_similarity
+SCORE_BOUND_SAME_EMB = 1e-4      # BASELINE.json bar, identical embeddings (measured 1.7e-8)
+SCORE_BOUND_END_TO_END = 2e-3    # bf16 towers vs fp32 CPU towers: score_src measured 2.5e-4, original_similarity 6.9e-4
 
 
 @pytest.fixture(scope="module")
@@ -134,5 +134,5 @@ def test_config2_full_step_records_vs_oracle(pkg, l14):
     print(f"[measured] configs[2] end to end (bf16 HIP towers vs fp32 CPU towers, 8 queries in the B=512 batch): "
           f"image min cos {mc_i:.6f} max|d| {md_i:.2e}; text min cos {mc_t:.6f} max|d| {md_t:.2e}; "
           f"|d score_src| {e_src:.2e} |d s0| {e_s0:.2e} |d overall_exp| {e_exp:.2e}")
-    assert mc_i > 0.999 and mc_t > 0.999
+    assert mc_i > 0.99998 and mc_t > 0.99993 and md_i < 1e-3 and md_t < 2.5e-3      # measured 0.999993 / 4.8e-4, 0.999967 / 1.2e-3
     assert e_src < SCORE_BOUND_END_TO_END and e_s0 < SCORE_BOUND_END_TO_END

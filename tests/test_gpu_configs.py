@@ -30,6 +30,9 @@ def test_config0_vit_b32_vs_cpu_reference_path(pkg, b32):
         ri = clip_oracle.vision_forward(vw, images, arch.vision.heads, arch.patch)
         rt = clip_oracle.text_forward(tw, tokens.view(-1, arch.ctx).long(), arch.text.heads).view(B, N + 1, -1)
     # bf16 towers (12 layers) vs the fp32 CPU towers on the SAME fp32 weights
+    print(f"[measured] ViT-B/32 configs[0] vs oracle (fp32w): image min cos {(fi.cpu() * ri).sum(-1).min().item():.6f} max|d| "
+          f"{(fi.cpu() - ri).abs().max().item():.2e}; text min cos {(ft.cpu() * rt).sum(-1).min().item():.6f} max|d| "
+          f"{(ft.cpu() - rt).abs().max().item():.2e}")
     assert (fi.cpu() * ri).sum(-1).min().item() > 0.999
     assert (ft.cpu() * rt).sum(-1).min().item() > 0.999
     bank = pkg.synth.plant_neighbours(pkg.synth.make_bank(R, arch.embed_dim, seed=7), rt.reshape(-1, arch.embed_dim), per_anchor=2)
@@ -46,6 +49,8 @@ def test_config0_vit_b32_vs_cpu_reference_path(pkg, b32):
     # (2) end to end vs the fp32 CPU path: bf16-tower tolerance on the scores
     ref = tvc_oracle.detect_batch(ri.numpy(), rt.numpy(), bank16.float().numpy(),
                                   checker=tvc_oracle.ConsistencyCheckerOracle(adaptive_threshold=False))
+    print(f"[measured] ViT-B/32 configs[0] end to end: |d score_src| {np.abs(rec[:, 5] - ref['score_src']).max():.2e} "
+          f"|d s0| {np.abs(rec[:, 0] - ref['original_similarity']).max():.2e}")
     assert np.abs(rec[:, 5] - ref["score_src"]).max() < 5e-3
     assert np.abs(rec[:, 0] - ref["original_similarity"]).max() < 5e-3
     assert (same["retrieval_indices"] >= 0).any()

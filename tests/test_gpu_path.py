@@ -222,6 +222,8 @@ def test_towers_vs_oracle(pkg):
         ri = clip_oracle.vision_forward(vr, imgs, arch.vision.heads, arch.patch)
         rt = clip_oracle.text_forward(tr, toks, arch.text.heads)
     assert torch.isfinite(gi).all() and torch.isfinite(gt).all()
+    print(f"[measured] ViT-T/16-test vs oracle (bf16w): image min cos {((gi * ri).sum(-1)).min().item():.6f} max|d| "
+          f"{(gi - ri).abs().max().item():.2e}; text min cos {((gt * rt).sum(-1)).min().item():.6f} max|d| {(gt - rt).abs().max().item():.2e}")
     assert ((gi * ri).sum(-1)).min().item() > 0.9995
     assert ((gt * rt).sum(-1)).min().item() > 0.9995
     assert (gi - ri).abs().max().item() < 2e-2

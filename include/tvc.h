@@ -291,12 +291,13 @@ int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches);
 
 /* ---- building blocks exported for parity tests and profiling --------- */
 
-/* out[j, i] = sum_k a[i, k] * b[j, k]  (+ bias[i]); a bf16 [I, K] ("weights"),
- * b bf16 [J, K] ("tokens"); K % 64 == 0.  epilogue: 0 = fp32 store,
- * 1 = bf16 store, 2 = bf16 quick-GELU, 3 = fp32 residual add (out += ...). */
+/* out[j, i] = sum_k a[i, k] * b[j, k]  (+ bias[i]); a bf16 [I, lda] ("weights"),
+ * b bf16 [J, ldb] ("tokens"); K % 64 == 0; lda / ldb = row strides in elements (0 = K, i.e. dense rows;
+ * otherwise >= K and a multiple of 8).  epilogue: 0 = fp32 store, 1 = bf16 store, 2 = bf16 quick-GELU,
+ * 3 = fp32 residual add (out += ...). */
 int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev,
                   const float* bias_dev, void* out_dev, int32_t I, int32_t J, int32_t K,
-                  int32_t ld_out, int32_t epilogue, void* stream);
+                  int64_t lda, int64_t ldb, int32_t ld_out, int32_t epilogue, void* stream);
 
 /* Multi-head attention over packed sequences: qkv bf16 [rows, 3*width]
  * (q | k | v), sequences of `seq_len` consecutive rows, out bf16 [rows, width]. */

@@ -19,7 +19,8 @@ from .pipeline import (DefensePipeline, MultiModalDetectionPipeline, PipelineCon
                        PipelineResult, create_defense_pipeline, create_detection_pipeline)
 from .ref_bank import ReferenceBank, ReferenceBankConfig, ReferenceItem, create_reference_bank
 from .retrieval import (MultiModalRetriever, RetrievalConfig, RetrievalRefConfig, RetrievalReferenceGenerator,
-                        create_retriever)
+                        create_retriever, extract_features)
+from .text_variants import TextVariantConfig, TextVariantGenerator
 from .variants import TemplateVariantGenerator
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -76,6 +76,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     const char* is_abase; const char* is_bbase;
     uint32_t va[2], vb[2];
     auto issue_tile = [&](int lin) {
+#ifdef TVC_RING_ALIAS
+        lin %= TVC_RING_ALIAS;       // diagnostic build only: every workgroup re-reads the first few tiles' operands (L2-resident)
+#endif
         const int jt = lin / nIt;
         const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
         is_abase = (const char*)(g.A + (int64_t)i0 * g.lda);

@@ -631,13 +631,16 @@ int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches) 
 }
 
 int tvc_gemm_bf16(tvc_handle* h, const uint16_t* a_dev, const uint16_t* b_dev, const float* bias_dev, void* out_dev,
-                  int32_t I, int32_t J, int32_t K, int32_t ld_out, int32_t epilogue, void* stream) {
+                  int32_t I, int32_t J, int32_t K, int64_t lda, int64_t ldb, int32_t ld_out, int32_t epilogue,
+                  void* stream) {
     if (!h) return TVC_E_INVALID;
+    if (lda == 0) lda = K;
+    if (ldb == 0) ldb = K;
     if (I <= 0 || J <= 0 || K <= 0 || K % 64 != 0 || !a_dev || !b_dev || !out_dev || ld_out < I ||
-        epilogue < 0 || epilogue > 3)
-        return fail(h, TVC_E_INVALID, "tvc_gemm_bf16: need K % 64 == 0, ld_out >= I");
+        epilogue < 0 || epilogue > 3 || lda < K || ldb < K || lda % 8 != 0 || ldb % 8 != 0)
+        return fail(h, TVC_E_INVALID, "tvc_gemm_bf16: need K % 64 == 0, ld_out >= I, lda / ldb >= K and multiples of 8");
     GemmLaunch g;
-    g.A = a_dev; g.lda = K; g.I = I; g.B = b_dev; g.ldb = K; g.J = J; g.K = K;
+    g.A = a_dev; g.lda = lda; g.I = I; g.B = b_dev; g.ldb = ldb; g.J = J; g.K = K;
     g.bias = bias_dev; g.out = out_dev; g.ldo = ld_out; g.epilogue = epilogue;
     {
         int rc = ensure(h, WS_SPLITK, (size_t)256 * 256 * 256 * 4);       // split-K scratch (small or tail tiles)

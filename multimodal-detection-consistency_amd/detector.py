@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .clip import CLIPConfig, CLIPModel
 from .engine import ConsistencyConfig
-from .variants import as_generator
+from .variants import as_generator, batch_variants
 
 SRC_WEIGHTS = {"text_variants": 0.4, "sd_reference": 0.4, "consistency": 0.2}   # src/detector.py:666-670
 
@@ -149,8 +149,11 @@ class AdversarialDetector:
 
     def batch_detect(self, images, texts: Sequence[str], methods: Optional[List[str]] = None,
                      variants: Optional[Sequence[Sequence[str]]] = None,
-                     reference_images: Optional[Sequence[Sequence[Any]]] = None) -> List[Dict[str, Any]]:
-        """src/detector.py:711-734, truly batched.  Queries are grouped by their variant count so
+                     reference_images: Optional[Sequence[Sequence[Any]]] = None,
+                     keep_features: Optional[Dict[str, torch.Tensor]] = None) -> List[Dict[str, Any]]:
+        """src/detector.py:711-734, truly batched.  ``keep_features`` (a dict) receives the device rows
+        ``image`` [n, D] and ``text`` [n, D] (the ORIGINAL texts) so that a caller needing them again
+        (the pipeline's retrieval step) does not encode the same texts twice.  Queries are grouped by their variant count so
         every group is one launch; ALL device work (image tower, text tower, reference-image tower,
         consistency kernels) is enqueued before the first device-to-host copy, and the host
         tokenises while the GPU runs the image tower."""
@@ -170,7 +173,8 @@ class AdversarialDetector:
         tv_on = "text_variants" in methods and self.config.use_text_variants
         sd_on = "sd_reference" in methods and (reference_images is not None or self.sd_generator is not None)
         if variants is None:
-            variants = [self._variants(t) if tv_on else [] for t in texts]
+            variants = batch_variants(self.text_augmenter, self.config.num_text_variants, texts) if tv_on \
+                else [[] for _ in texts]
         groups: Dict[int, List[int]] = {}
         for i, v in enumerate(variants):
             groups.setdefault(len(v), []).append(i)
@@ -184,6 +188,11 @@ class AdversarialDetector:
             ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
             sel = fi if len(ids) == n else fi[torch.as_tensor(ids, device=fi.device)].contiguous()
             pending.append((N, ids, eng.consistency(sel, ft, cfg)))
+            if keep_features is not None:
+                if "text" not in keep_features:
+                    keep_features["text"] = torch.empty((n, ft.shape[-1]), dtype=ft.dtype, device=ft.device)
+                    keep_features["image"] = fi
+                keep_features["text"][torch.as_tensor(ids, device=ft.device)] = ft[:, 0]
         # SD-reference method: arithmetic in scope (src/detector.py:528-553), producing the reference
         # images is not -- they come from the caller or an injected generator.  ONE encode of all
         # reference images, one consistency launch per distinct count (cos(image, ref_j) = record words 0, 12..).
@@ -475,7 +484,8 @@ class MultiModalDefenseDetector:
         x, _ = clip._images_to_device(images)
         fi = eng.encode_image(x, True)                      # enqueued first: overlaps the host work below
         if variants is None:
-            variants = [self._variants(t) for t in texts]
+            variants = batch_variants(self.text_variant_generator, self.config.text_variant_count, texts) \
+                if self.config.use_text_variants else [[] for _ in texts]
         per_query: List[Optional[Dict[str, float]]] = [None] * n
         extra: List[Optional[Dict]] = [None] * n
         groups: Dict[int, List[int]] = {}

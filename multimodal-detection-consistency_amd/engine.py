@@ -350,12 +350,16 @@ class TVCEngine:
 
     # ---- building blocks (parity tests / profiling) ----------------------
     def gemm(self, a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """out[j, i] = sum_k a[i, k] b[j, k] (+ bias[i]); a, b bf16."""
+             out: Optional[torch.Tensor] = None, k: Optional[int] = None) -> torch.Tensor:
+        """out[j, i] = sum_k a[i, k] b[j, k] (+ bias[i]); a, b bf16.  ``k``: multiply only the first k columns
+        (the operands' row strides stay their full widths: padded leading dimensions)."""
         a = _require_cuda(a, torch.bfloat16, "a")
         b = _require_cuda(b, torch.bfloat16, "b")
-        I, K = a.shape
-        J = b.shape[0]
+        I, lda = a.shape
+        J, ldb = b.shape
+        K = k if k is not None else lda
+        if k is None and lda != ldb:
+            raise ValueError("a and b must have the same number of columns (or pass k)")
         if out is None:
             out = torch.empty((J, I), dtype=torch.float32 if epilogue in (0, 3) else torch.bfloat16, device=self.device)
             if epilogue == 3:
@@ -363,7 +367,7 @@ class TVCEngine:
         if bias is not None:
             bias = _require_cuda(bias, torch.float32, "bias")
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.tvc_gemm_bf16(self.handle, _ptr(a), _ptr(b), _ptr(bias), _ptr(out), I, J, K,
+            self._check(self.lib.tvc_gemm_bf16(self.handle, _ptr(a), _ptr(b), _ptr(bias), _ptr(out), I, J, K, lda, ldb,
                                                out.shape[1], epilogue, _stream()))
         return out
 

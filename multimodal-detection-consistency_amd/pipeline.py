@@ -28,7 +28,7 @@ from .clip import CLIPConfig, CLIPModel
 from .detector import AdversarialDetector, DetectorConfig
 from .metrics import DetectionEvaluator
 from .retrieval import MultiModalRetriever, RetrievalConfig
-from .variants import as_generator
+from .variants import as_generator, batch_variants
 
 
 @dataclass
@@ -148,21 +148,21 @@ class MultiModalDetectionPipeline:
             variants = None
             if "text_augment" in steps:
                 t0 = time.time()
-                gen = as_generator(self.text_augmenter, dc.num_text_variants)
-                variants = [gen(t) for t in texts]
+                variants = batch_variants(self.text_augmenter, dc.num_text_variants, texts)
                 dt = (time.time() - t0) / max(n, 1)
                 for r, v in zip(results, variants):
                     r.text_variants, r.text_augment_time = v, dt
                 self._count("text_augment", n, dt * n)
-            if "retrieval" in steps and self.retriever is not None and self.retriever._bank_is == "image":
+            do_retrieval = "retrieval" in steps and self.retriever is not None and self.retriever._bank_is == "image"
+            do_detection = "detection" in steps and self.detector is not None
+            # retrieval needs the L2-normalised rows of the ORIGINAL texts, which the detection step encodes
+            # anyway: when both run (and normalise alike) the rows are handed over instead of encoded twice
+            share = do_retrieval and do_detection and self.retriever.config.normalize_features and \
+                self.retriever.clip_model is self.clip_model
+            if do_retrieval and not share:
                 t0 = time.time()
                 got = self.retriever.batch_retrieve_images_by_texts(list(texts), top_k=5)     # src/pipeline.py:450-453
-                dt = (time.time() - t0) / max(n, 1)
-                for r, (paths, scores) in zip(results, got):
-                    r.retrieved_images, r.retrieval_scores = paths, scores
-                    r.retrieved_texts = [r.original_text] * len(paths)                        # :468
-                    r.retrieval_time = dt
-                self._count("retrieval", n, dt * n)
+                self._fill_retrieval(results, got, (time.time() - t0) / max(n, 1), n)
             ref_images = None
             if "sd_reference" in steps and self.sd_generator is not None:
                 t0 = time.time()
@@ -176,10 +176,15 @@ class MultiModalDetectionPipeline:
                 t0 = time.time()
                 if variants is None and "text_variants" in methods:
                     methods = [m for m in methods if m != "text_variants"]
+                kept: Optional[Dict[str, torch.Tensor]] = {} if share else None
                 det = self.detector.batch_detect(images, list(texts), methods=methods,
                                                  variants=variants if "text_variants" in methods else [[] for _ in texts],
-                                                 reference_images=ref_images)
+                                                 reference_images=ref_images, keep_features=kept)
                 dt = (time.time() - t0) / max(n, 1)
+                if share:
+                    t1 = time.time()
+                    got = self.retriever.batch_retrieve_images_by_features(kept["text"], top_k=5)  # src/pipeline.py:450-453
+                    self._fill_retrieval(results, got, (time.time() - t1) / max(n, 1), n)
                 for r, d in zip(results, det):
                     r.is_adversarial = d["is_adversarial"]
                     r.detection_score = d["aggregated_score"]
@@ -201,6 +206,13 @@ class MultiModalDetectionPipeline:
             self.pipeline_stats["failed_processed"] += n - ok
             self.pipeline_stats["total_time"] += total
         return results
+
+    def _fill_retrieval(self, results, got, dt: float, n: int) -> None:
+        for r, (paths, scores) in zip(results, got):
+            r.retrieved_images, r.retrieval_scores = paths, scores
+            r.retrieved_texts = [r.original_text] * len(paths)                                # src/pipeline.py:468
+            r.retrieval_time = dt
+        self._count("retrieval", n, dt * n)
 
     def _count(self, step: str, n: int, seconds: float) -> None:
         with self._lock:

@@ -129,6 +129,13 @@ class MultiModalRetriever:
         idx, sim = self._search(q, top_k)
         return [([self.image_paths[i] for i in r[r >= 0]], s[r >= 0].astype(float).tolist()) for r, s in zip(idx, sim)]
 
+    def batch_retrieve_images_by_features(self, text_features: torch.Tensor, top_k: Optional[int] = None):
+        """The same search for text rows that are already encoded (the pipeline hands over the original
+        texts' rows of the detection step instead of encoding them a second time)."""
+        idx, sim = self._search(text_features.contiguous(), top_k or self.config.top_k)
+        paths = self.image_paths
+        return [([paths[i] for i in r[r >= 0]], s[r >= 0].astype(float).tolist()) for r, s in zip(idx, sim)]
+
     def retrieve(self, text: str, k: int = 5):
         """Name used by the efficiency harness (experiments/run_experiments.py:3143)."""
         return self.retrieve_images_by_text(text, top_k=k)
@@ -155,6 +162,36 @@ class MultiModalRetriever:
             d2 = np.maximum(tn ** 2 + (inn ** 2).T - 2 * dot, 0.0)
             return 1.0 / (1.0 + np.sqrt(d2))
         raise ValueError(f"unsupported similarity metric: {self.config.similarity_metric}")
+
+
+def extract_features(clip_model: CLIPModel, dataloader, encode_batch: int = 512):
+    """scripts/build_faiss_indices.py:59-120 (``IndexBuilder.extract_features``): batches of
+    ``{'image': Tensor [b,3,S,S], 'text': list[str], 'image_id': list}`` -> (image_features [R, D],
+    text_features [R, D], image_ids), both L2-normalised fp32 numpy (the arrays ``build_dataset_indices``
+    saves as ``image_features.npy`` / ``text_features.npy``, :186-192).  Images and texts are regrouped into
+    ``encode_batch`` rows per tower launch."""
+    imgs, toks, ids = [], [], []
+    fi, ft = [], []
+
+    def flush():
+        if imgs:
+            x = torch.cat(imgs)
+            fi.append(clip_model.engine.encode_image(x, True))
+            ft.append(clip_model.encode_tokens(torch.cat(toks), True))
+            imgs.clear(); toks.clear()
+
+    n = 0
+    for batch in dataloader:
+        x, _ = clip_model._images_to_device(batch["image"])
+        imgs.append(x); toks.append(clip_model.tokenize(list(batch["text"]))); ids.extend(list(batch["image_id"]))
+        n += x.shape[0]
+        if n >= encode_batch:
+            flush(); n = 0
+    flush()
+    D = clip_model.arch.embed_dim
+    f_i = torch.cat(fi).cpu().numpy() if fi else np.zeros((0, D), np.float32)
+    f_t = torch.cat(ft).cpu().numpy() if ft else np.zeros((0, D), np.float32)
+    return f_i, f_t, ids
 
 
 def create_retriever(config: Optional[RetrievalConfig] = None, **kw) -> MultiModalRetriever:
@@ -189,6 +226,7 @@ class RetrievalReferenceGenerator:
         self.feature_cache: Dict[int, List[Dict[str, Any]]] = {}
         self.bank_name = f"retrieval_ref:{id(self):x}"  # own bank slot on the (shared) engine
         self.retrieval_stats = {"total_queries": 0, "successful_retrievals": 0, "cache_hits": 0}
+        self.reference_db_path = Path(reference_db_path) if reference_db_path is not None else None
         if features is not None:
             self._register(torch.as_tensor(features), metadata or [])
         elif reference_db_path is not None:
@@ -210,6 +248,64 @@ class RetrievalReferenceGenerator:
         self.reference_metadata = meta
         self.clip_model.engine.set_bank(feats.float().to(self.clip_model.device) if feats.dtype != torch.bfloat16
                                         else feats.to(self.clip_model.device), name=self.bank_name)
+
+    # -- bank construction -------------------------------------------------------
+    def _save_reference_database(self, path: Optional[str] = None) -> Path:
+        """experiments/defenses/retrieval_ref.py:442-457: ``features.npy`` (dense fp32 [R, D], rows
+        L2-normalised) + ``metadata.json`` -- the only on-disk bank format the hot path reads."""
+        d = Path(path or self.reference_db_path)
+        d.mkdir(parents=True, exist_ok=True)
+        feats = self.reference_features
+        feats = feats.float().cpu().numpy() if isinstance(feats, torch.Tensor) else np.asarray(feats, np.float32)
+        np.save(d / "features.npy", feats.astype(np.float32, copy=False))
+        with open(d / "metadata.json", "w", encoding="utf-8") as f:
+            json.dump(self.reference_metadata, f, ensure_ascii=False, indent=2)
+        return d
+
+    def build_reference_database(self, dataset_loader, max_samples: Optional[int] = None, save_interval: int = 1000,
+                                 encode_batch: int = 512, save: bool = True) -> bool:
+        """experiments/defenses/retrieval_ref.py:459-540 and scripts/build_faiss_indices.py:59-120: stream a
+        dataset through the image tower, L2-normalise, stack, save, register as this generator's bank.
+        ``dataset_loader`` yields ``{'images': Tensor [b,3,S,S] | list of Tensor/PIL, 'texts': list[str]}``.
+        The reference encodes ONE image per call (:482-487); here the loader's batches are regrouped into
+        ``encode_batch`` images per ``tvc_encode_image`` launch (the tower's efficient batch), metadata
+        entries are the reference's ``{'text', 'index', 'batch_idx'}``."""
+        clip = self.clip_model
+        feats: List[torch.Tensor] = []
+        meta: List[Dict[str, Any]] = []
+        pend: List[torch.Tensor] = []
+        n_pend = 0
+        count = 0
+
+        def flush():
+            nonlocal pend, n_pend
+            if n_pend:
+                x = torch.cat(pend) if len(pend) > 1 else pend[0]
+                feats.append(clip.engine.encode_image(x, True))              # L2-normalised rows (:489)
+                pend, n_pend = [], 0
+
+        for batch_idx, batch in enumerate(dataset_loader):
+            images, texts = batch["images"], batch["texts"]
+            if max_samples is not None and count >= max_samples:
+                break
+            take = len(texts) if max_samples is None else min(len(texts), max_samples - count)
+            x, _ = clip._images_to_device(images[:take] if isinstance(images, torch.Tensor) else list(images)[:take])
+            for j in range(take):
+                meta.append({"text": texts[j], "index": count + j, "batch_idx": batch_idx})
+            count += take
+            while x.shape[0]:
+                room = encode_batch - n_pend
+                pend.append(x[:room]); n_pend += min(room, x.shape[0])
+                x = x[room:]
+                if n_pend >= encode_batch:
+                    flush()
+        flush()
+        if not feats:
+            return False                                                      # :534-536
+        self._register(torch.cat(feats) if len(feats) > 1 else feats[0], meta)
+        if save and getattr(self, "reference_db_path", None) is not None:
+            self._save_reference_database()
+        return True
 
     def retrieve_references_batch(self, texts: Sequence[str]) -> List[List[Dict[str, Any]]]:
         eng = self.clip_model.engine

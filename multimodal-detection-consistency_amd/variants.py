@@ -46,3 +46,13 @@ def as_generator(obj, num_variants: int) -> Callable[[str], List[str]]:
     if callable(obj):
         return lambda t: list(obj(t))[:num_variants]
     raise TypeError("variant generator must be callable or expose generate_variants()/augment()")
+
+
+def batch_variants(obj, num_variants: int, texts) -> List[List[str]]:
+    """Variants of many texts: ONE call when the generator can batch (``batch_generate_variants``,
+    experiments/defenses/text_variants.py:383 -- the CLIP-filtered generator then encodes all candidates
+    in one launch), otherwise one call per text."""
+    if obj is not None and hasattr(obj, "batch_generate_variants"):
+        return [list(v)[:num_variants] for v in obj.batch_generate_variants(list(texts))]
+    gen = as_generator(obj, num_variants)
+    return [gen(t) for t in texts]

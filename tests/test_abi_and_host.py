@@ -207,3 +207,27 @@ def test_pgd_fixture_matches_the_oracle(pkg):
     assert np.abs(ref["score_src"] - o["score_src"][pick]).max() < 1e-5
     assert np.abs(ref["overall_exp"] - o["overall_exp"][pick]).max() < 1e-5
     assert abs(O.detection_metrics(o["score_src"], fx["labels"])["auc"] - float(o["auc_src"])) < 1e-12
+
+
+def test_text_variant_rules_follow_the_reference(pkg):
+    """experiments/defenses/text_variants.py:110-176,305-343 (string rules; the reference file itself cannot be
+    imported: syntax error at :297).  Expected strings worked out by hand from the reference's rules."""
+    g = pkg.TextVariantGenerator(config=pkg.TextVariantConfig(filter_quality=False, variant_count=100))
+    syn = g._generate_synonym_variants("A big Dog runs FAST.")
+    assert syn == ["A large Dog runs FAST.", "A huge Dog runs FAST.", "A enormous Dog runs FAST.",
+                   "A big Canine runs FAST.", "A big Puppy runs FAST.", "A big Hound runs FAST.",
+                   "A big Dog runs QUICK", "A big Dog runs RAPID", "A big Dog runs SWIFT"]
+    par = g._generate_paraphrase_variants("a picture of two cats")
+    assert par[:6] == [f"{p} a picture of two cats" for p in ("a view of", "an image featuring", "a photograph showing",
+                                                               "a snapshot of", "a depiction of", "a representation of")]
+    assert par[6:10] == ["a photo of a picture of two cats", "an image showing a picture of two cats",
+                         "a picture of a picture of two cats", "a scene with a picture of two cats"]
+    assert par[10:] == ["two cats"]                                  # core extraction (:318-341)
+    assert g._generate_reorder_variants("one two three four five six seven eight nine") == []   # > 8 words
+    ro = g._generate_reorder_variants("red car parked outside")
+    assert 1 <= len(ro) <= 3 and all(sorted(v.split()) == sorted("red car parked outside".split()) for v in ro)
+    assert not g._basic_filter("A Red Car", "a red car") and not g._basic_filter("12 34", "x") and g._basic_filter("a blue car", "a red car")
+    out = g.generate_variants("a small cat")                          # no filter: candidates in rule order, cut
+    assert out[:3] == ["a tiny cat", "a little cat", "a mini cat"] and len(out) == 3 + 3 + 10 + 2
+    with pytest.raises(ValueError):
+        pkg.TextVariantGenerator().generate_variants("a small cat")   # the semantic filter needs a clip_model

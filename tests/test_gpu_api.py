@@ -296,3 +296,86 @@ def test_bench_gpus_flag_runs_two_ranks_on_one_gpu(pkg):
         assert len(lines) == 1
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 32
+
+
+def test_text_variant_generator_clip_filter(pkg, clip):
+    """rule candidates + the CLIP semantic window + ranking
+    (experiments/defenses/text_variants.py:206-284), all candidates of all texts in ONE text encode.  The
+    similarities are checked against the fp32 CPU oracle tower on the same tokens; selection and order
+    against the reference's logic applied to them."""
+    from oracle import clip_oracle
+    texts = ["a small cat on a red sofa", "a photo of a big dog", "fast car", "people"]
+    # random-init towers put related strings close together: widen the window so that it selects something
+    cfg = pkg.TextVariantConfig(variant_count=6, diversity_threshold=0.1, similarity_threshold=0.97)
+    gen = pkg.TextVariantGenerator(clip_model=clip, config=cfg)
+    cands = [[v for v in gen.candidates(t) if gen._basic_filter(v, t)] for t in texts]
+    gen._rng.seed(cfg.seed)                                           # the same reorderings again below
+    sims = gen.similarities(texts, cands)
+    tw = clip_oracle.round_gemm_weights_to_bf16(pkg.synth.make_clip_weights(clip.arch, seed=0)[1])
+    worst = 0.0
+    for t, c, s in zip(texts, cands, sims):
+        with torch.no_grad():
+            f = clip_oracle.text_forward(tw, clip.tokenize([t] + c), clip.arch.text.heads)
+        ref = (f[1:] * f[0]).sum(-1).numpy()
+        worst = max(worst, float(np.abs(ref - s).max()))
+    print(f"[measured] text-text cosines, HIP vs oracle: max |d| {worst:.2e}")
+    assert worst < 3e-3
+    got = gen.batch_generate_variants(texts)
+    for t, c, s, g in zip(texts, cands, sims, got):
+        seen, want = set(), []
+        for v, x in zip(c, s):
+            if cfg.diversity_threshold < x < cfg.similarity_threshold and v not in seen:
+                seen.add(v); want.append((v, x))
+        want.sort(key=lambda p: p[1], reverse=True)
+        assert g == [v for v, _ in want][:cfg.variant_count]
+        assert len(set(g)) == len(g) and t not in g
+    assert any(got)
+    q = gen.evaluate_variant_quality(texts[0], got[0] or cands[0][:3])
+    assert set(q) == {"variant_count", "similarity_stats", "diversity_stats", "quality_score"} and 0.0 <= q["quality_score"] <= 1.0
+    # drop-in as the detector's augmenter: one batched generation for the whole batch
+    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=4), clip_model=clip,
+                                  text_augmenter=gen)
+    res = det.batch_detect(pkg.synth.make_images(4, 64, seed=3).cuda(), texts)
+    assert len(res) == 4 and all("consistency" in r["detection_scores"] for r in res)
+
+
+def test_build_reference_database_roundtrip(pkg, clip, tmp_path):
+    """SURVEY.md 8f rank 2 (experiments/defenses/retrieval_ref.py:442-540, scripts/build_faiss_indices.py:59-120):
+    stream a dataset through the image tower, write features.npy + metadata.json in the reference's format,
+    load it back through RetrievalReferenceGenerator and retrieve."""
+    import json
+    R, bs = 1300, 100
+    imgs = pkg.synth.make_images(R, 64, seed=70)
+    caps = [f"caption number {i}" for i in range(R)]
+
+    def loader():
+        for i in range(0, R, bs):
+            yield {"images": imgs[i:i + bs], "texts": caps[i:i + bs]}
+
+    gen = pkg.RetrievalReferenceGenerator(clip, reference_db_path=str(tmp_path / "db"))
+    assert gen.build_reference_database(loader(), max_samples=1234, encode_batch=512)
+    feats = np.load(tmp_path / "db" / "features.npy")
+    meta = json.load(open(tmp_path / "db" / "metadata.json", encoding="utf-8"))
+    assert feats.shape == (1234, 128) and feats.dtype == np.float32 and len(meta) == 1234
+    assert meta[0] == {"text": "caption number 0", "index": 0, "batch_idx": 0} and meta[1233]["batch_idx"] == 12
+    assert np.abs(np.linalg.norm(feats, axis=1) - 1.0).max() < 1e-5
+    direct = clip.encode_image(imgs[:1234].cuda()).cpu().numpy()
+    assert np.array_equal(feats[:512], direct[:512])          # the same 512-image launches (batch invariant towers)
+    assert np.abs(feats - direct).max() < 1e-6
+    # round trip: a fresh generator reads the directory and retrieves
+    gen2 = pkg.RetrievalReferenceGenerator(clip, reference_db_path=str(tmp_path / "db"),
+                                           config=pkg.RetrievalRefConfig(similarity_threshold=-1.0))
+    refs = gen2.retrieve_references("caption number 7")
+    q = clip.encode_text(["caption number 7"]).numpy()[0]
+    S = feats.astype(np.float64) @ q.astype(np.float64)
+    order = np.argsort(-S, kind="stable")[:5]
+    assert [r["index"] for r in refs] == order.tolist() and refs[0]["metadata"]["index"] == int(order[0])
+    assert np.abs(np.array([r["similarity"] for r in refs]) - S[order]).max() < 1e-5
+    # scripts/build_faiss_indices.py:59-120 form
+    def loader2():
+        for i in range(0, 300, 64):
+            yield {"image": imgs[i:i + 64], "text": caps[i:i + 64], "image_id": list(range(i, min(i + 64, 300)))}
+    fi, ft, ids = pkg.extract_features(clip, loader2(), encode_batch=128)
+    assert fi.shape == ft.shape == (300, 128) and ids == list(range(300))
+    assert np.abs(fi - direct[:300]).max() < 1e-6
+    assert np.abs(ft - clip.encode_text(caps[:300]).numpy()).max() < 1e-6

@@ -331,7 +331,7 @@ def main():
         prof = eng.profile_end()
         g = prof["gemm"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_ring_kernel<EPI> (all tvc GEMM launches of a step: ring + the few small gemm_bf16_kernel ones)", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": "gemm_ring3_kernel<EPI> (all tvc GEMM launches of a step: the persistent ring kernels + the few small gemm_bf16_kernel ones)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                 "traffic": None, "launches_per_step": g["launches"],
                 "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
@@ -346,7 +346,7 @@ def main():
             if files and a.model == "ViT-L/14" and B == 512 and N == 8 and R == 1_000_000 and not a.shard_bank:
                 pm = json.load(open(files[-1]))
                 ring = [(v["launches"], v["hbm_MB_per_launch_corrected"]) for kk, v in pm.items()
-                        if kk.startswith("gemm_ring_kernel")]
+                        if kk.startswith("gemm_ring")]
                 if ring:
                     roof["traffic"] = round(sum(n * mb for n, mb in ring) / sum(n for n, _ in ring) / 1e3, 3)
                     roof["traffic_unit"] = "GB per launch (PMC, launch-weighted mean over the ring GEMMs)"

@@ -19,6 +19,7 @@ struct GemmLaunch {
     int64_t ldo = 0;
     int epilogue = TVC_EPI_F32;
     bool no_solo = false;          // internal: remainder launch of a split GEMM
+    bool b_rows_padded = false;    // B has readable (garbage) rows up to the next multiple of 256 beyond J
     // optional scratch for the split-K tail (see launch_gemm_bf16); nullptr disables it
     float* splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;

@@ -167,7 +167,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16;
+        g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
             const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
@@ -177,7 +177,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16;
+        g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 8.0);
@@ -185,11 +185,11 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16;
+        g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
-        g.bias = w.b2; g.out = D2; g.ldo = d; g.epilogue = TVC_EPI_BF16;
+        g.bias = w.b2; g.out = D2; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         pending = true;
     }
@@ -198,6 +198,9 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
 
 int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq, int wso) {
     int rc;
+    // GEMM operands get readable rows up to the next multiple of 256 (+ one tile): the 64-deep ring form stages
+    // whole 256-row tiles without clamping; what it reads beyond the last row only reaches outputs never stored
+    rows = (rows + 255) / 256 * 256 + 256;
     if ((rc = ensure(h, (Slot)(WS_X + wso), (size_t)rows * a.width * 4))) return rc;
     if ((rc = ensure(h, (Slot)(WS_H + wso), (size_t)rows * a.width * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_QKV + wso), (size_t)rows * a.width * 3 * 2))) return rc;
@@ -291,7 +294,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
     if (B == 0) return TVC_OK;
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk, 0))) return rc;
-    if ((rc = ensure(h, WS_PATCH, (size_t)chunk * P * Kp * 2))) return rc;
+    if ((rc = ensure(h, WS_PATCH, ((size_t)chunk * P + 512) * Kp * 2))) return rc;      // + tile padding, as ensure_tower_ws
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int n = (B - b0 < chunk) ? B - b0 : chunk;
         const float* pix = pix_dev + (size_t)b0 * 3 * m.image_size * m.image_size;
@@ -301,7 +304,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         HIP_TRY(launch_im2col(pix, Pm, n, m.image_size, m.patch, Kp, st));
         GemmLaunch g;
         g.A = h->vw.patch_w; g.lda = Kp; g.I = d; g.B = Pm; g.ldb = Kp; g.J = n * P; g.K = Kp;
-        g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32;
+        g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));

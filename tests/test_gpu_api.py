@@ -374,7 +374,8 @@ def test_build_reference_database_roundtrip(pkg, clip, tmp_path):
     # scripts/build_faiss_indices.py:59-120 form
     def loader2():
         for i in range(0, 300, 64):
-            yield {"image": imgs[i:i + 64], "text": caps[i:i + 64], "image_id": list(range(i, min(i + 64, 300)))}
+            j = min(i + 64, 300)
+            yield {"image": imgs[i:j], "text": caps[i:j], "image_id": list(range(i, j))}
     fi, ft, ids = pkg.extract_features(clip, loader2(), encode_batch=128)
     assert fi.shape == ft.shape == (300, 128) and ids == list(range(300))
     assert np.abs(fi - direct[:300]).max() < 1e-6

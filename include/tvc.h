@@ -134,9 +134,14 @@ const char* tvc_last_error(tvc_handle* h);
  * variants (the layout of pipeline.detect: original + N variants).  A causal tower gives two texts
  * identical hidden states on their common token prefix, so a variant keeps only the rows from its
  * first differing token on and attends to the original's rows for the shared prefix.  Outputs are
- * bit-identical; needs text packing and T % G == 0, otherwise it is ignored for that call. */
+ * bit-identical; needs text packing and T % G == 0, otherwise it is ignored for that call.
+ * TVC_OPT_POOLED_LAST_LAYER (default 1): both towers are pooled at ONE token (the class token / the EOT token), so
+ * in their LAST layer only that token's attention output, out-projection, ln_2 and MLP are ever read.  With the
+ * option on, those are computed for the pooled rows only (K and V still come from every token): the embeddings
+ * are unchanged (same fp32 sums in the same order) while 10/12 of the last layer's GEMM work is not done.  0 runs
+ * the last layer over every token like the others. */
 enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
-       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5 };
+       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
 
 /* Bytes of device workspace currently held by the handle. */

@@ -21,6 +21,7 @@ TVC_REC_HEAD, TVC_REC_MAXREF = 12, 16
 TVC_ABI_VERSION, TVC_MAX_BANKS, TVC_MAX_TOPK = 2, 8, 128
 TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS, TVC_OPT_BANK_FILTER = 1, 2, 3, 4
 TVC_OPT_TEXT_GROUP = 5
+TVC_OPT_POOLED_LAST_LAYER = 6
 
 
 class TVCError(RuntimeError):

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                                                         uint16_t* __restrict__ out,
                                                         const int32_t* __restrict__ starts, int T_fixed,
                                                         int heads, int n_items, int k_bytes, int region_bytes,
-                                                        const int32_t* __restrict__ pfx, int n_seq) {
+                                                        const int32_t* __restrict__ pfx, int n_seq,
+                                                        int pool_mode, const int32_t* __restrict__ pool_row) {
     // WPS waves cooperate on one (sequence, head) item; a workgroup holds 4 / WPS items,
     // each with its own K/V region in LDS.  Short text sequences use WPS = 1.
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,7 +125,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     const int tr_off = (4 * g + (r16 >> 2)) * ATT_VROW + ((r16 & 3) << 3);
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // dh^-0.5 * log2(e)
     const int own = T - P;                     // query rows (all of them unless a prefix is shared)
-    const int NQ = (own + 15) >> 4;
+    // Pooled form (the LAST layer of a tower: only the pooled token's output is ever read -- the class token
+    // of the vision tower, the EOT token of the text tower): ONE query per sequence, at absolute position
+    // `pool_pos`, its output written to the compact row `seq`.  All 16 query columns of the one block carry
+    // that query; column 0 stores.
+    int pool_pos = 0;
+    if (pool_mode == 2) pool_pos = starts ? T - 1 : __builtin_amdgcn_readfirstlane(pool_row[seq]) - (int)row0;
+    const int NQ = pool_mode ? 1 : (own + 15) >> 4;
     // Masking costs nothing after the MFMA: the accumulator is INITIALISED with 0 or -inf
     // (-inf + q.k = -inf).  Only the last key tile holds keys >= T.
     f32x4_t pen_tail;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
 
     // Q fragments come straight from HBM/L2: fetch the NEXT block's while this one computes
     auto q_ptr = [&](int qb) {
+        if (pool_mode) return qkv + key_row(pool_pos) * ld + h * ATT_DH + 8 * g;
         int qrow = qb * 16 + r16;
         qrow = qrow < own ? qrow : own - 1;
         return qkv + (row0 + qrow) * ld + h * ATT_DH + 8 * g;
@@ -144,8 +152,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         const int qr = qb * 16 + r16;
         const bf16x8_t bq0 = nq0, bq1 = nq1;
         if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
-        // causal: keys up to the block's last query position P + qb*16 + 15
-        const int nt_c = ((P + qb * 16 + 15) >> 4) + 1;
+        // absolute positions of the block's first / last query and of this lane's query
+        const int qmin = pool_mode ? pool_pos : P + qb * 16;
+        const int qmax = pool_mode ? pool_pos : qmin + 15;
+        const int qpos = pool_mode ? pool_pos : P + qr;
+        // causal: keys up to the block's last query position
+        const int nt_c = (qmax >> 4) + 1;
         const int nt_q = EXACT ? MAXT : (CAUSAL ? (nt_c < NT ? nt_c : NT) : NT);
 
         f32x4_t s[MAXT];
@@ -177,10 +189,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (t < nt_q) {
                 f32x4_t c0 = (t == NT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (CAUSAL && t * 16 + 15 > P + qb * 16) {      // tile reaches past the block's first query position
+                if (CAUSAL && t * 16 + 15 > qmin) {      // tile reaches past the block's first query position
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (t * 16 + 4 * g + r > P + qr) c0[r] = -INFINITY;
+                        if (t * 16 + 4 * g + r > qpos) c0[r] = -INFINITY;
                 }
                 const char* kr = ldsK + (t * 16 + r16) * ATT_KROW;
                 const bf16x8_t a0 = *(const bf16x8_t*)(kr + sw0);
@@ -241,9 +253,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 }
             }
         }
-        if (qr < own) {
+        if (pool_mode ? (r16 == 0) : (qr < own)) {
             const float inv = 1.0f / lsum;
-            uint16_t* op = out + (row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;
+            uint16_t* op = out + (pool_mode ? (int64_t)seq : row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;
 #pragma unroll
             for (int md = 0; md < 4; ++md) {
                 u32x2_t w;
@@ -257,7 +269,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
 
 template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
-                             int max_T, int heads, hipStream_t stream, const int32_t* pfx = nullptr) {
+                             int max_T, int heads, hipStream_t stream, const int32_t* pfx = nullptr,
+                             int pool_mode = 0, const int32_t* pool_row = nullptr) {
     const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
     const int k_bytes = NT * 16 * ATT_KROW;
     const int region = k_bytes + NP * 32 * ATT_VROW;
@@ -272,27 +285,32 @@ static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* 
     if (attr_st != hipSuccess) return attr_st;
     const int n_items = n_seq * heads;
     hipLaunchKernelGGL((attention_kernel<MAXT, CAUSAL, WPS, EXACT, NW>), dim3((n_items + IPW - 1) / IPW), dim3(NW * 64), lds, stream,
-                       qkv, out, starts, T, heads, n_items, k_bytes, region, pfx, n_seq);
+                       qkv, out, starts, T, heads, n_items, k_bytes, region, pfx, n_seq, pool_mode, pool_row);
     return hipGetLastError();
 }
 
 // starts == nullptr: n_seq sequences of seq_len rows each; otherwise sequence s owns rows
 // [starts[s], starts[s+1]) (device array of n_seq + 1 ints) and seq_len is the MAXIMUM length.
+// pool_mode 0: every row's output, token-major [rows, width].  1 / 2: only the pooled token of every sequence
+// (1 = its first token, 2 = its EOT token: the last packed row, or packed row pool_row[s] for dense rows), written
+// to the compact row s of `out` [n_seq, width] -- what the LAST layer of a tower needs.
 hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len,
-                            int heads, int causal, hipStream_t stream, const int32_t* pfx) {
+                            int heads, int causal, hipStream_t stream, const int32_t* pfx, int pool_mode,
+                            const int32_t* pool_row) {
     if (n_seq <= 0) return hipSuccess;
-    if (seq_len < 1 || seq_len > 288 || heads < 1) return hipErrorInvalidValue;
+    if (seq_len < 1 || seq_len > 288 || heads < 1 || pool_mode < 0 || pool_mode > 2) return hipErrorInvalidValue;
+    if (pool_mode == 2 && !starts && !pool_row) return hipErrorInvalidValue;
     const int NT = (seq_len + 15) / 16;
     if (causal) {
         if (pfx && !starts) return hipErrorInvalidValue;
-        if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
-        if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
-        return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx);
+        if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
+        if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
+        return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
     }
-    if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);   // ViT-L/14: 257 tokens
-    if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);     // ViT-B/32: 50 tokens
-    if (NT <= 2) return launch_one<2, false, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
-    if (NT <= 4) return launch_one<4, false, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
-    if (NT <= 6) return launch_one<6, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
-    return launch_one<18, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream);
+    if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);   // ViT-L/14: 257 tokens
+    if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);     // ViT-B/32: 50 tokens
+    if (NT <= 2) return launch_one<2, false, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);
+    if (NT <= 4) return launch_one<4, false, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);
+    if (NT <= 6) return launch_one<6, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);
+    return launch_one<18, false, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);
 }

@@ -21,14 +21,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                                                         const uint16_t* __restrict__ delta2, int write_x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
-                                                        uint16_t* __restrict__ y, int rows, int d) {
+                                                        uint16_t* __restrict__ y, int rows, int d,
+                                                        int delta_compact) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t src_row = row_idx ? (int64_t)row_idx[row] : (int64_t)row;
     f32x4_t* xr = (f32x4_t*)(x + src_row * x_row_stride);
-    const u32x2_t* dr = delta ? (const u32x2_t*)(delta + src_row * x_row_stride) : nullptr;   // same [rows, d] element offset as x
-    const u32x2_t* dr2 = delta2 ? (const u32x2_t*)(delta2 + src_row * x_row_stride) : nullptr;
+    // deltas: the same element offset as x, or (delta_compact) [rows, d] in output-row order
+    const int64_t doff = delta_compact ? (int64_t)row * d : src_row * x_row_stride;
+    const u32x2_t* dr = delta ? (const u32x2_t*)(delta + doff) : nullptr;
+    const u32x2_t* dr2 = delta2 ? (const u32x2_t*)(delta2 + doff) : nullptr;
     const int nv = d >> 2;
     f32x4_t v[4];
     float s = 0.f;
@@ -90,12 +93,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream, const uint16_t* delta2) {
+                            hipStream_t stream, const uint16_t* delta2, int delta_compact) {
     if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, delta2,
-                       write_x, g, b, y, rows, d);
+                       write_x, g, b, y, rows, d, delta_compact);
     return hipGetLastError();
 }
 

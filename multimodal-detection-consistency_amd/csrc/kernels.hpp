@@ -28,9 +28,10 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 
 // ---- elementwise.hip
 // y = LN(x [+ delta [+ delta2]]); with a delta and write_x the sum is written back to x (residual stream)
+// delta_compact: the delta rows are [rows, d] in OUTPUT row order (a pooled last layer) instead of x's row layout
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream, const uint16_t* delta2 = nullptr);
+                            hipStream_t stream, const uint16_t* delta2 = nullptr, int delta_compact = 0);
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream);
 hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
@@ -58,8 +59,10 @@ hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int 
 // ---- attention.hip
 // pfx (optional, causal packed rows only): sequence s = pfx[s] rows starting at packed row
 // pfx[n_seq + s] (shared prefix, keys only) followed by its own rows [starts[s], starts[s+1]) (keys + queries)
+// pool_mode 1 / 2: only the pooled token's output per sequence (first token / EOT token), compact [n_seq, width]
 hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq,
-                            int seq_len, int heads, int causal, hipStream_t stream, const int32_t* pfx = nullptr);
+                            int seq_len, int heads, int causal, hipStream_t stream, const int32_t* pfx = nullptr,
+                            int pool_mode = 0, const int32_t* pool_row = nullptr);
 
 // ---- bank.hip
 struct BankSearchLaunch {

@@ -18,8 +18,8 @@ thread_local std::string g_create_error;
 enum Slot {
     // tower workspaces exist twice (vision, text: + WS_TOWER_N) so that the two towers can run
     // concurrently on two streams
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_TOWER_N,
-    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK,
+    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_POOL, WS_TOWER_N,
+    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK, WS_TPOOL,
     WS_PATCH, WS_EOT, WS_STARTS, WS_PFX, WS_LENS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
@@ -65,6 +65,7 @@ struct tvc_handle {
     int max_chunk_texts = 4608;
     bool pack_text = true;     // TVC_OPT_TEXT_PACKING
     int text_group = 0;        // TVC_OPT_TEXT_GROUP: texts come in groups of this many sharing prefixes (0: off)
+    bool pooled_last = true;   // TVC_OPT_POOLED_LAST_LAYER
     bool prof = false;
     std::vector<ProfRec> prof_recs;
 };
@@ -140,9 +141,27 @@ bool tower_ok(const tvc_tower_arch& a) {
 // One transformer tower over `rows` packed token rows (n_seq sequences of seq_len).
 // Sequences: n_seq x seq_len dense rows, or (starts != nullptr) packed rows with
 // `total_rows` rows in all and seq_len = the maximum length.
+// pool_mode (TVC_OPT_POOLED_LAST_LAYER): 1 / 2 = the caller only reads the pooled token of every sequence (first
+// token / EOT token at packed row pool_row[s]).  The LAST layer then computes attention, out-proj, ln_2 and the
+// MLP for those n_seq rows only (its K and V still need every token): outputs identical, 10/12 of the layer's
+// GEMM work and all but one query of its attention dropped.  Its deltas are left COMPACT ([n_seq, d], WS_POOL)
+// for the caller's final LayerNorm; `pooled_out` reports that.
+struct PoolBufs { uint16_t *Hc, *D1c, *H2c, *MLPc, *D2c; };
+PoolBufs pool_bufs(tvc_handle* h, const tvc_tower_arch& a, int n_seq, int wso) {
+    uint16_t* p = (uint16_t*)h->ws[WS_POOL + wso].p;
+    const size_t nd = ((size_t)n_seq + 256) * a.width;            // rows padded to a GEMM tile
+    PoolBufs b;
+    b.Hc = p; b.D1c = p + nd; b.H2c = p + 2 * nd; b.D2c = p + 3 * nd; b.MLPc = p + 4 * nd;
+    return b;
+}
+size_t pool_bytes(const tvc_tower_arch& a, int n_seq) {
+    return (((size_t)n_seq + 256) * a.width * 4 + ((size_t)n_seq + 256) * a.mlp) * 2;
+}
+
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
                int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st,
-               const int32_t* pfx = nullptr) {
+               const int32_t* pfx = nullptr, int pool_mode = 0, const int32_t* pool_row = nullptr,
+               int64_t pool_x_stride = 0) {
     const int d = a.width;
     const int rows = starts ? total_rows : n_seq * seq_len;
     float* X = (float*)h->ws[WS_X + wso].p;
@@ -169,6 +188,29 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+        if (pool_mode && l == a.layers - 1) {
+            const PoolBufs pb = pool_bufs(h, a, n_seq, wso);
+            {
+                const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
+                ProfScope ps(h, st, TVC_PROF_ATTENTION, 4.0 * n_seq * a.heads * avg_len * 64);
+                HIP_TRY(launch_attention(QKV, pb.Hc, starts, n_seq, seq_len, a.heads, causal, st, pfx, pool_mode, pool_row));
+            }
+            g = GemmLaunch();
+            g.A = w.wo; g.lda = d; g.I = d; g.B = pb.Hc; g.ldb = d; g.J = n_seq; g.K = d;
+            g.bias = w.bo; g.out = pb.D1c; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            HIP_TRY(launch_layernorm(X, pool_row ? d : pool_x_stride, pool_row, pb.D1c, 0, w.ln2_g, w.ln2_b, pb.H2c, n_seq, d,
+                                     st, nullptr, 1));
+            g = GemmLaunch();
+            g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = pb.H2c; g.ldb = d; g.J = n_seq; g.K = d;
+            g.bias = w.b1; g.out = pb.MLPc; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16; g.b_rows_padded = true;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            g = GemmLaunch();
+            g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = pb.MLPc; g.ldb = a.mlp; g.J = n_seq; g.K = a.mlp;
+            g.bias = w.b2; g.out = pb.D2c; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            return TVC_OK;
+        }
         {
             const double avg_len = starts ? (double)rows / n_seq : (double)seq_len;
             const double fl = 4.0 * n_seq * a.heads * avg_len * avg_len * 64 * (causal ? 0.5 : 1.0);
@@ -211,6 +253,7 @@ int ensure_tower_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_
     // fp32 partial tiles of the split-K paths (<= 256 partial tiles of 256 KiB): small batches split
     // every tile over K, big ones (opt-in) the left-over tile columns
     if ((rc = ensure(h, (Slot)(WS_SPLITK + wso), (size_t)256 * 256 * 256 * 4))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_POOL + wso), pool_bytes(a, n_seq)))) return rc;
     return TVC_OK;
 }
 
@@ -308,13 +351,20 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
         HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b,
                                       (float*)h->ws[WS_X].p, n, T, d, st));
-        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, 0, st))) return rc;
+        const int pool = h->pooled_last ? 1 : 0;                  // only the class token (row b*T) is pooled
+        if ((rc = run_layers(h, a, h->vw.layers, n, T, 0, nullptr, 0, 0, st, nullptr, pool, nullptr, (int64_t)T * d))) return rc;
         // ln_post on the class rows, projection, L2 norm
         uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
         // ln_post on the class rows (row b*T), folding in the last layer's two pending deltas
-        HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr,
-                                 (const uint16_t*)h->ws[WS_DELTA].p, 0, h->vw.ln_post_g, h->vw.ln_post_b, Hc, n, d, st,
-                                 (const uint16_t*)h->ws[WS_DELTA2].p));
+        if (pool) {
+            const PoolBufs pb = pool_bufs(h, a, n, 0);
+            HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, pb.D1c, 0, h->vw.ln_post_g,
+                                     h->vw.ln_post_b, Hc, n, d, st, pb.D2c, 1));
+        } else {
+            HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr,
+                                     (const uint16_t*)h->ws[WS_DELTA].p, 0, h->vw.ln_post_g, h->vw.ln_post_b, Hc, n, d, st,
+                                     (const uint16_t*)h->ws[WS_DELTA2].p));
+        }
         g = GemmLaunch();
         g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)b0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
@@ -370,11 +420,18 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
         }
         HIP_TRY(launch_text_embed(tok, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_TX].p, eot, starts, n, ctx, d,
                                   m.vocab, st, pfx));
-        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st, pfx))) return rc;
+        const int pool = h->pooled_last ? 2 : 0;                  // only the EOT row of every text is pooled
+        if ((rc = run_layers(h, a, h->tw.layers, n, max_len, 1, starts, total_rows, WS_TOWER_N, st, pfx, pool, eot, d))) return rc;
         uint16_t* Hc = (uint16_t*)h->ws[WS_TCLS].p;
-        HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
-                                 h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st,
-                                 (const uint16_t*)h->ws[WS_TDELTA2].p));
+        if (pool) {
+            const PoolBufs pb = pool_bufs(h, a, n, WS_TOWER_N);
+            HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, pb.D1c, 0, h->tw.ln_final_g, h->tw.ln_final_b, Hc,
+                                     n, d, st, pb.D2c, 1));
+        } else {
+            HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, eot, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
+                                     h->tw.ln_final_g, h->tw.ln_final_b, Hc, n, d, st,
+                                     (const uint16_t*)h->ws[WS_TDELTA2].p));
+        }
         GemmLaunch g;
         g.A = h->tw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = n; g.K = d;
         g.out = out_dev + (size_t)t0 * m.embed_dim; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
@@ -595,6 +652,7 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
     switch (option) {
         case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
         case TVC_OPT_BANK_FILTER: h->bank_filter = value != 0; return TVC_OK;
+        case TVC_OPT_POOLED_LAST_LAYER: h->pooled_last = value != 0; return TVC_OK;
         case TVC_OPT_TEXT_GROUP:
             if (value < 0 || value > 4096) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TEXT_GROUP out of range");
             h->text_group = (int)value; return TVC_OK;

@@ -465,3 +465,33 @@ def test_bank_search_clustered_1m_bank(gpu_engine):
     # differing positions only where two rows tie within the fp32 rounding of the re-scoring
     assert ((got_s - best_v).abs()[~exact] < 2e-6).all()
     assert (sim[:M // 2, 0] > 0.5).float().mean().item() > 0.9      # near-centre queries do find their cluster
+
+
+@pytest.mark.parametrize("model", ["ViT-T/16-test", "ViT-B/32"])
+def test_pooled_last_layer_is_bit_identical(pkg, model):
+    """TVC_OPT_POOLED_LAST_LAYER: the last layer of a tower computes attention / out-proj / ln_2 / MLP for the
+    pooled token only (class token, EOT token).  Same fp32 sums in the same order -> the embeddings must equal
+    the all-token computation bit for bit: vision, text dense / packed / with prefix sharing (incl. a variant
+    identical to its original, whose EOT row is the original's)."""
+    arch = pkg.get_arch(model)
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, vw, tw)
+    imgs = pkg.synth.make_images(5, arch.image_size, seed=1).cuda()
+    toks = pkg.synth.make_tokens(6, 3, arch.ctx, seed=5, min_len=1, max_len=60)
+    toks[1, 2] = toks[1, 0]                                   # a variant equal to its original
+    toks[2, 1, 1:70] = 17; toks[2, 1, 70] = 49407; toks[2, 1, 71:] = 0     # a long one
+    toks = toks.reshape(-1, arch.ctx).cuda()
+    out = {}
+    for pooled in (1, 0):
+        eng.set_option(pkg._lib.TVC_OPT_POOLED_LAST_LAYER, pooled)
+        res = [eng.encode_image(imgs), eng.encode_image(imgs, normalize=False)]
+        for packing in (1, 0):
+            eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, packing)
+            res.append(eng.encode_text(toks))
+            res.append(eng.encode_text(toks, group=4))
+        eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 1)
+        out[pooled] = [r.cpu() for r in res]
+    for a, b in zip(out[1], out[0]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.equal(out[1][2], out[1][3]) and torch.equal(out[1][2], out[1][4])      # packed == shared == dense
+    eng.close()

@@ -22,6 +22,9 @@
 #define ATT_DH 64
 #define ATT_KROW 128     // K image: 64 bf16 per row
 #define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
+#ifndef TVC_ATT_ASM_MAX
+#define TVC_ATT_ASM_MAX 0
+#endif
 
 // EXACT: every sequence has exactly MAXT key tiles (fixed-length, non-causal: the vision tower).
 // The per-tile guards become compile-time true, so the 16-key tiles of a query block are
@@ -177,11 +180,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
             }
             float m0 = -INFINITY, m1 = -INFINITY;
+#if TVC_ATT_ASM_MAX
+            // Experiment (measured 350 vs 333 us per ViT-L layer call, i.e. SLOWER, kept for the record): the row
+            // maximum as 2 * MAXT v_max3_f32 in asm -- `fmaxf` makes hipcc canonicalise every MFMA output first
+            // (121 max instructions where 34 do).  hipcc pads no hazards for inline asm, so the MFMA -> VALU-read
+            // wait states are spent explicitly behind a scheduling fence; that fence also stops the compiler
+            // from keeping K fragments in registers across query blocks and from interleaving the maxima with
+            // the second MFMA pass, which costs more than the 87 instructions save.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m0) : "v"(s[t][0]), "v"(s[t][1]));
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m1) : "v"(s[t][2]), "v"(s[t][3]));
+            }
+#else
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 m0 = fmaxf(m0, fmaxf(s[t][0], s[t][1]));
                 m1 = fmaxf(m1, fmaxf(s[t][2], s[t][3]));
             }
+#endif
             mx = fmaxf(m0, m1);
         } else {
 #pragma unroll
@@ -207,21 +226,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mxs = mx * scale_log2;
 
-        float lsum = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             if (t < nt_q) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // exp2(s * c - max * c): one FMA + raw v_exp_f32 (args <= 0; -inf -> 0)
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2, -mxs));
-                    s[t][r] = p;
-                    lsum += p;
-                }
+                for (int r = 0; r < 4; ++r)     // exp2(s * c - max * c): one FMA + raw v_exp_f32 (args <= 0; -inf -> 0)
+                    s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2, -mxs));
             }
         }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        // The softmax denominator comes out of the matrix pipe: a fifth "V^T tile" of ones gives
+        // sum_k 1 * P[k, q] in every accumulator row (the pipe is ~20 % busy in this kernel, its 68 fp32 adds
+        // and two cross-lane shuffles per query block sat on the vector issue slots that bound it).  The sum is
+        // over the SAME bf16-rounded probabilities the numerator uses.
+        f32x4_t osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
         f32x4_t o[4];
 #pragma unroll
@@ -251,8 +269,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                     a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
                     o[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, o[md], 0, 0, 0);
                 }
+                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, osum, 0, 0, 0);
             }
         }
+        const float lsum = osum[0];          // every row of the ones tile holds the column (= query) sum
         if (pool_mode ? (r16 == 0) : (qr < own)) {
             const float inv = 1.0f / lsum;
             uint16_t* op = out + (pool_mode ? (int64_t)seq : row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;

@@ -429,6 +429,31 @@ def main():
                     "defense.batch_detect = encode + bank search of the B*(N+1) text rows + consistency + the stateful "
                     "host-side ConsistencyChecker"}
 
+    if extras:
+        # ---- the attack inner loop: forward + input gradient + projected sign step per image,
+        # at the same tower, batch 32 (src/attacks/pgd_attack.py:42) -- an extra line, not the headline metric
+        pb = min(32, B)
+        clean = images[:pb].contiguous()
+        adv, mom = clean.clone(), torch.zeros_like(clean)
+        tf = eng.encode_text(tokens[:pb, 0].contiguous())
+        g_out = (tf / pb).contiguous()
+
+        def pgd_iter():
+            eng.encode_image_grad(adv, True)
+            g = eng.encode_image_backward(g_out)
+            eng.pgd_step(adv, clean, g, mom, 8 / 255, 2 / 255, 0.9, 0.0, 1.0, False)
+
+        ks = 10
+        eng.profile_begin()
+        pgd_iter(); sync()
+        prof = eng.profile_end()
+        d_pgd, _ = timed(pgd_iter, ks, 2)
+        fwd_flop = prof["gemm"]["work"] / pb
+        out["pgd_inner_loop"] = {"image_steps_per_s": round(pb * ks / d_pgd, 1), "batch": pb, "ms_per_step": round(d_pgd / ks * 1e3, 2),
+                                 "gemm_tflops_in_step": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1),
+                                 "gemm_gflop_per_image_step": round(fwd_flop / 1e9, 1),
+                                 "note": "forward + per-layer recompute + the four dX GEMMs per layer; no weight gradients"}
+
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         nq = min(B, 64)
         cores = host_cpus()             # more threads than the cgroup quota only thrash

@@ -238,6 +238,33 @@ int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim
 int tvc_cosine_matrix(tvc_handle* h, const float* x_dev, int32_t N, const float* y_dev, int32_t M,
                       int32_t D, float* out_dev, void* stream);
 
+/* ---- input gradient of the vision tower -------- */
+
+/* What `encode_image_tensor(x, requires_grad=True)` + `loss.backward()` give a white-box attack
+ * (src/attacks/pgd_attack.py:456-486, src/attacks/hubness_attack.py:269-424, src/models/clip_model.py:200-221):
+ * the embedding AND d(loss)/d(pixels).  Only the INPUT gradient exists -- the weights are frozen in every
+ * attack of the reference -- so no weight-gradient GEMM is ever run.
+ *
+ * tvc_encode_image_grad: same result as tvc_encode_image (every layer runs over every token; B must fit one
+ *   pass, B <= TVC_OPT_MAX_CHUNK_IMAGES) and keeps, inside the handle, each layer's fp32 input rows
+ *   (layers * B * T * width * 4 bytes), the un-normalised embedding and the ln_post input.  pix_dev must stay
+ *   valid and unchanged until the matching backward (the stem is recomputed from it).
+ * tvc_encode_image_backward: grad_out fp32 [B, D] = d(loss)/d(out of the LAST tvc_encode_image_grad on this
+ *   handle) -> grad_pix fp32 [B, 3, S, S] in the preprocessed (normalised) pixel space.  Each layer's forward is
+ *   recomputed from its saved input (activation checkpointing per layer: 2 x the forward's GEMM work once more,
+ *   plus 2 x for the four dX GEMMs), gradients travel between GEMMs in bf16 and accumulate along the residual
+ *   stream in fp32.  Deterministic (no atomics).  May be called repeatedly for different grad_out. */
+int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, void* stream);
+int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* grad_pix_dev, void* stream);
+
+/* One projected-gradient step on a batch of B images of n elements each, in place on adv_dev
+ * (src/attacks/pgd_attack.py:500-521):
+ *   momentum_dev != NULL:  m = mu * m + grad / |grad|_1 (per image);  step direction sign(m);  else sign(grad)
+ *   adv = clamp(clean + clamp(adv +- alpha * sign - clean, -eps, eps), clip_min, clip_max)   ('-' when targeted) */
+int tvc_pgd_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const float* grad_dev, float* momentum_dev,
+                 int32_t B, int64_t n, float eps, float alpha, float mu, float clip_min, float clip_max,
+                 int32_t targeted, void* stream);
+
 /* ---- per-query consistency (K4, K6, K7) ------------------------------ */
 
 typedef struct {
@@ -312,6 +339,16 @@ int tvc_attention(tvc_handle* h, const uint16_t* qkv_dev, uint16_t* out_dev,
 /* y bf16 [rows, d] = LayerNorm(x fp32 [rows, d]) * g + b, eps 1e-5. */
 int tvc_layernorm(tvc_handle* h, const float* x_dev, const float* g_dev, const float* b_dev,
                   uint16_t* y_dev, int32_t rows, int32_t d, void* stream);
+
+/* Backward of tvc_attention (non-causal, fixed-length sequences, head_dim 64): qkv as the forward saw it,
+ * dout bf16 [rows, width] = gradient w.r.t. the attention output, dqkv bf16 [rows, 3*width] (dq | dk | dv). */
+int tvc_attention_backward(tvc_handle* h, const uint16_t* qkv_dev, const uint16_t* dout_dev, uint16_t* dqkv_dev,
+                           int32_t n_seq, int32_t seq_len, int32_t heads, void* stream);
+
+/* LayerNorm input gradient: x fp32 [rows, d] (the forward's input), dy bf16 [rows, d], gamma fp32 [d],
+ * dres fp32 [rows, d] or NULL (added: the residual path's gradient), dx fp32 [rows, d]. */
+int tvc_layernorm_backward(tvc_handle* h, const float* x_dev, const uint16_t* dy_dev, const float* g_dev,
+                           const float* dres_dev, float* dx_dev, int32_t rows, int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,8 +7,9 @@ HIP kernels for gfx950 reached through the C-ABI in ``include/tvc.h``.
 There is no CPU fallback: without ``libtvc_hip.so`` and a GPU every compute call
 raises ``TVCError``.
 """
-from . import _lib, sharding, synth
+from . import _lib, attacks, sharding, synth
 from ._lib import TVCError, build
+from .attacks import PGDAttackConfig, PGDAttacker, create_pgd_attacker
 from .arch import ARCHS, ClipArch, Tower, get_arch
 from .clip import CLIPConfig, CLIPModel
 from .detector import (AdversarialDetector, ConsistencyChecker, DetectionConfig, DetectorConfig,

@@ -131,6 +131,22 @@ def weights_from_hf_state_dict(sd: Dict[str, torch.Tensor], arch: ClipArch):
     return vision, text
 
 
+class _EncodeImageFn(torch.autograd.Function):
+    """pixels -> embedding with the HIP forward / input-gradient kernels behind torch.autograd."""
+
+    @staticmethod
+    def forward(ctx, x, engine, normalize):
+        xc = x.detach().to(torch.float32).contiguous()
+        out = engine.encode_image_grad(xc, normalize)
+        ctx.engine, ctx.generation, ctx.in_dtype = engine, engine._grad_generation, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.engine.encode_image_backward(grad_out.contiguous(), ctx.generation)
+        return g.to(ctx.in_dtype), None, None
+
+
 class CLIPModel:
     """The encoder object the detector / retriever / runners are handed."""
 
@@ -204,9 +220,17 @@ class CLIPModel:
         return out if on_dev else out.cpu()
 
     def encode_image_tensor(self, x: torch.Tensor, requires_grad: bool = False) -> torch.Tensor:
-        if requires_grad:
-            raise NotImplementedError("backward through the HIP towers is out of scope (attacks only, SURVEY.md 8f)")
-        return self.encode_image(x)
+        """Tensor in, tensor out (src/detector.py:626).  ``requires_grad=True`` (src/attacks/pgd_attack.py:254,459,480,
+        src/attacks/hubness_attack.py:586): the result carries an autograd node whose backward is the HIP input-gradient
+        pass (``tvc_encode_image_backward``) -- ``loss.backward()`` fills ``x.grad`` as it does in the reference.  Only
+        the pixels receive a gradient (the weights are frozen); one differentiable batch at a time per model."""
+        if not requires_grad:
+            return self.encode_image(x)
+        if not x.is_cuda:
+            raise ValueError("encode_image_tensor(requires_grad=True) needs a device tensor (no CPU fallback)")
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        return _EncodeImageFn.apply(x, self.engine, bool(self.config.normalize))
 
     def encode_tokens(self, tokens: torch.Tensor, normalize: Optional[bool] = None, group: int = 0) -> torch.Tensor:
         """int [T, ctx] -> device tensor [T, D].  ``group`` = N + 1 when the rows are consecutive

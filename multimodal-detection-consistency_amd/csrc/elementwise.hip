@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
                                                         uint16_t* __restrict__ y, int rows, int d,
-                                                        int delta_compact) {
+                                                        int delta_compact, float* __restrict__ xsum_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                 v[i][3] += __uint_as_float(dd[1] & 0xffff0000u);
             }
             if (write_x && (dr || dr2)) xr[c] = v[i];
+            if (xsum_out) ((f32x4_t*)(xsum_out + (int64_t)row * d))[c] = v[i];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
 
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream, const uint16_t* delta2, int delta_compact) {
+                            hipStream_t stream, const uint16_t* delta2, int delta_compact, float* xsum_out) {
     if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, delta2,
-                       write_x, g, b, y, rows, d, delta_compact);
+                       write_x, g, b, y, rows, d, delta_compact, xsum_out);
     return hipGetLastError();
 }
 

@@ -31,7 +31,8 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 // delta_compact: the delta rows are [rows, d] in OUTPUT row order (a pooled last layer) instead of x's row layout
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream, const uint16_t* delta2 = nullptr, int delta_compact = 0);
+                            hipStream_t stream, const uint16_t* delta2 = nullptr, int delta_compact = 0,
+                            float* xsum_out = nullptr);     // xsum_out: fp32 [rows, d] receives x (+ deltas), compact
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream);
 hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
@@ -116,3 +117,19 @@ hipError_t launch_consistency(const float* img, const float* txt, int B, int N, 
                               const int32_t* ref_idx, const float* ref_sim, const float* ref_feat,
                               int ks, int kf, const ConsistencyParams& p, float* rec, int rec_stride,
                               hipStream_t stream);
+
+// ---- backward.hip / attention_bwd.hip: input gradient (dX only) of the vision tower
+hipError_t launch_layernorm_bwd(const float* x, int64_t x_row_stride, const uint16_t* delta, const void* dy, int dy_fp32,
+                                const float* gamma, const float* dres, float* dx, uint16_t* dx16, int rows, int d,
+                                int64_t out_row_stride, hipStream_t stream);
+hipError_t launch_lnpre_bwd(const float* patch_out, const float* pos, const float* gamma, const float* dy,
+                            uint16_t* dpatch, int B, int T, int d, hipStream_t stream);
+hipError_t launch_gelu_bwd(uint16_t* dm, const uint16_t* u, int64_t n, hipStream_t stream);
+hipError_t launch_gelu_fwd(const uint16_t* u, uint16_t* out, int64_t n, hipStream_t stream);
+hipError_t launch_l2norm_bwd(const float* x, const float* dy, uint16_t* dx16, int rows, int d, int normalize, hipStream_t stream);
+hipError_t launch_col2im(const float* dcols, float* dpix, int B, int S, int patch, int Kp, hipStream_t stream);
+hipError_t launch_transpose_bf16(const uint16_t* in, uint16_t* out, int R, int C, hipStream_t stream);
+hipError_t launch_pgd_step(float* adv, const float* clean, const float* grad, float* mom, int B, int64_t n, float eps,
+                           float alpha, float mu, float lo, float hi, int targeted, hipStream_t stream);
+hipError_t launch_attention_bwd(const uint16_t* qkv, const uint16_t* dao, uint16_t* dqkv, float* stats_ws, int n_seq, int T,
+                                int heads, hipStream_t stream);

@@ -23,6 +23,8 @@ enum Slot {
     WS_PATCH, WS_EOT, WS_STARTS, WS_PFX, WS_LENS,
     WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
     WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
+    // input-gradient path (vision tower): saved layer inputs, gradient stream, scratch
+    WS_GSAVE, WS_GOUT, WS_GXL, WS_GDX, WS_G16, WS_GMLP2, WS_GDQKV, WS_GSTATS, WS_GSMALL, WS_GPATCH,
     WS_COUNT
 };
 
@@ -66,6 +68,11 @@ struct tvc_handle {
     bool pack_text = true;     // TVC_OPT_TEXT_PACKING
     int text_group = 0;        // TVC_OPT_TEXT_GROUP: texts come in groups of this many sharing prefixes (0: off)
     bool pooled_last = true;   // TVC_OPT_POOLED_LAST_LAYER
+    // input-gradient state: transposed GEMM weights (built on first use), what the last tvc_encode_image_grad saw
+    std::vector<void*> wT;     // per layer: wqkvT, woT, w1T, w2T; then projT, patchT
+    int grad_B = 0;
+    int grad_normalize = 0;
+    const float* grad_pix = nullptr;
     bool prof = false;
     std::vector<ProfRec> prof_recs;
 };
@@ -161,7 +168,7 @@ size_t pool_bytes(const tvc_tower_arch& a, int n_seq) {
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
                int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st,
                const int32_t* pfx = nullptr, int pool_mode = 0, const int32_t* pool_row = nullptr,
-               int64_t pool_x_stride = 0) {
+               int64_t pool_x_stride = 0, float* save_x = nullptr) {
     const int d = a.width;
     const int rows = starts ? total_rows : n_seq * seq_len;
     float* X = (float*)h->ws[WS_X + wso].p;
@@ -184,6 +191,8 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
             HIP_TRY(launch_layernorm(X, d, nullptr, pending ? D1 : nullptr, 1, w.ln1_g, w.ln1_b, H, rows, d, st,
                                      pending ? D2 : nullptr));
         }
+        // input-gradient mode: the residual stream as layer l sees it (X now holds it: ln_1 folded the pending deltas)
+        if (save_x) HIP_TRY(hipMemcpyAsync(save_x + (size_t)l * rows * d, X, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
@@ -309,6 +318,7 @@ int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision, con
 void tvc_destroy(tvc_handle* h) {
     if (!h) return;
     for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
+    for (void* p : h->wT) if (p) (void)hipFree(p);
     for (auto& bk : h->banks) {
         if (bk.owned) (void)hipFree(bk.owned);
         if (bk.bounds) (void)hipFree(bk.bounds);
@@ -644,6 +654,197 @@ int tvc_consistency(tvc_handle* h, const float* img_dev, const float* txt_dev, i
                                        rec_dev, tvc_rec_stride(N), (hipStream_t)stream);
     if (st != hipSuccess) return fail(h, st == hipErrorInvalidValue ? TVC_E_INVALID : TVC_E_HIP,
                                       std::string("tvc_consistency: ") + hipGetErrorString(st));
+    return TVC_OK;
+}
+
+// ---- input gradient of the vision tower -------------------------------------------
+namespace {
+int build_transposed_weights(tvc_handle* h, hipStream_t st) {
+    if (!h->wT.empty()) return TVC_OK;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.vision;
+    const int d = a.width, Kp = (3 * m.patch * m.patch + 63) / 64 * 64;
+    auto tr = [&](const uint16_t* w, int R, int C, void** out) -> int {
+        HIP_TRY(hipMalloc(out, (size_t)R * C * 2));
+        HIP_TRY(launch_transpose_bf16(w, (uint16_t*)*out, R, C, st));
+        return TVC_OK;
+    };
+    std::vector<void*> t((size_t)a.layers * 4 + 2, nullptr);
+    int rc = TVC_OK;
+    for (int l = 0; l < a.layers && !rc; ++l) {
+        const tvc_layer_weights& w = h->vw.layers[l];
+        if ((rc = tr(w.wqkv, 3 * d, d, &t[l * 4 + 0]))) break;      // [3d, d] -> [d, 3d]
+        if ((rc = tr(w.wo, d, d, &t[l * 4 + 1]))) break;
+        if ((rc = tr(w.w1, a.mlp, d, &t[l * 4 + 2]))) break;        // [mlp, d] -> [d, mlp]
+        if ((rc = tr(w.w2, d, a.mlp, &t[l * 4 + 3]))) break;        // [d, mlp] -> [mlp, d]
+    }
+    if (!rc) rc = tr(h->vw.proj, m.embed_dim, d, &t[(size_t)a.layers * 4]);           // [D, d] -> [d, D]
+    if (!rc) rc = tr(h->vw.patch_w, d, Kp, &t[(size_t)a.layers * 4 + 1]);             // [d, Kp] -> [Kp, d]
+    if (rc) { for (void* p : t) if (p) (void)hipFree(p); return rc; }
+    h->wT = t;
+    return TVC_OK;
+}
+}  // namespace
+
+int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->has_vision) return fail(h, TVC_E_STATE, "tvc_encode_image_grad: handle has no vision tower");
+    if (B < 1 || !pix_dev || !out_dev) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: bad arguments");
+    if (B > h->max_chunk_images) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: B exceeds TVC_OPT_MAX_CHUNK_IMAGES (one pass only)");
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.vision;
+    const int gside = m.image_size / m.patch, P = gside * gside, T = P + 1, d = a.width;
+    const int Kp = (3 * m.patch * m.patch + 63) / 64 * 64;
+    const int64_t rows = (int64_t)B * T;
+    int rc;
+    if ((rc = ensure_tower_ws(h, a, rows, B, 0))) return rc;
+    if ((rc = ensure(h, WS_PATCH, ((size_t)B * P + 512) * Kp * 2))) return rc;
+    if ((rc = ensure(h, WS_GSAVE, (size_t)a.layers * rows * d * 4))) return rc;
+    if ((rc = ensure(h, WS_GOUT, (size_t)B * m.embed_dim * 4))) return rc;
+    if ((rc = ensure(h, WS_GXL, (size_t)B * d * 4))) return rc;
+    uint16_t* Pm = (uint16_t*)h->ws[WS_PATCH].p;
+    float* patch_out = (float*)h->ws[WS_MLP].p;
+    if ((size_t)B * P * d * 4 > h->ws[WS_MLP].n) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: mlp < 2*width unsupported");
+    HIP_TRY(launch_im2col(pix_dev, Pm, B, m.image_size, m.patch, Kp, st));
+    GemmLaunch g;
+    g.A = h->vw.patch_w; g.lda = Kp; g.I = d; g.B = Pm; g.ldb = Kp; g.J = B * P; g.K = Kp;
+    g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32; g.b_rows_padded = true;
+    HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+    HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b, (float*)h->ws[WS_X].p, B, T, d, st));
+    if ((rc = run_layers(h, a, h->vw.layers, B, T, 0, nullptr, 0, 0, st, nullptr, 0, nullptr, 0, (float*)h->ws[WS_GSAVE].p))) return rc;
+    uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
+    HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, (const uint16_t*)h->ws[WS_DELTA].p, 0,
+                             h->vw.ln_post_g, h->vw.ln_post_b, Hc, B, d, st, (const uint16_t*)h->ws[WS_DELTA2].p, 0,
+                             (float*)h->ws[WS_GXL].p));
+    g = GemmLaunch();
+    g.A = h->vw.proj; g.lda = d; g.I = m.embed_dim; g.B = Hc; g.ldb = d; g.J = B; g.K = d;
+    g.out = h->ws[WS_GOUT].p; g.ldo = m.embed_dim; g.epilogue = TVC_EPI_F32;
+    HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+    HIP_TRY(hipMemcpyAsync(out_dev, h->ws[WS_GOUT].p, (size_t)B * m.embed_dim * 4, hipMemcpyDeviceToDevice, st));
+    if (normalize) HIP_TRY(launch_l2norm_rows(out_dev, B, m.embed_dim, st));
+    h->grad_B = B; h->grad_normalize = normalize; h->grad_pix = pix_dev;
+    return TVC_OK;
+}
+
+int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* grad_pix_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->has_vision || h->grad_B < 1) return fail(h, TVC_E_STATE, "tvc_encode_image_backward: call tvc_encode_image_grad first");
+    if (!grad_out_dev || !grad_pix_dev) return fail(h, TVC_E_INVALID, "tvc_encode_image_backward: NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.vision;
+    const int B = h->grad_B, gside = m.image_size / m.patch, P = gside * gside, T = P + 1, d = a.width, D = m.embed_dim;
+    const int Kp = (3 * m.patch * m.patch + 63) / 64 * 64;
+    const int64_t rows = (int64_t)B * T;
+    const int64_t rows_pad = (rows + 255) / 256 * 256 + 256;
+    int rc;
+    if ((rc = build_transposed_weights(h, st))) return rc;
+    if ((rc = ensure(h, WS_GDX, (size_t)rows_pad * d * 4))) return rc;
+    if ((rc = ensure(h, WS_G16, (size_t)rows_pad * d * 2))) return rc;
+    if ((rc = ensure(h, WS_GMLP2, (size_t)rows_pad * a.mlp * 2))) return rc;
+    if ((rc = ensure(h, WS_GDQKV, (size_t)rows_pad * 3 * d * 2))) return rc;
+    if ((rc = ensure(h, WS_GSTATS, (size_t)rows * a.heads * 16))) return rc;
+    if ((rc = ensure(h, WS_GSMALL, ((size_t)B + 256) * (D + d) * 2))) return rc;
+    if ((rc = ensure(h, WS_GPATCH, ((size_t)B * P + 512) * (size_t)(Kp > d ? Kp : d) * 4))) return rc;
+    float* X = (float*)h->ws[WS_X].p;
+    uint16_t* H = (uint16_t*)h->ws[WS_H].p;
+    uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
+    uint16_t* U = (uint16_t*)h->ws[WS_MLP].p;
+    uint16_t* D1 = (uint16_t*)h->ws[WS_DELTA].p;
+    uint16_t* D2 = (uint16_t*)h->ws[WS_DELTA2].p;
+    float* dX = (float*)h->ws[WS_GDX].p;
+    uint16_t* G16 = (uint16_t*)h->ws[WS_G16].p;
+    uint16_t* dM = (uint16_t*)h->ws[WS_GMLP2].p;
+    uint16_t* dQKV = (uint16_t*)h->ws[WS_GDQKV].p;
+    const float* saveX = (const float*)h->ws[WS_GSAVE].p;
+    auto gemm = [&](const void* A, int64_t lda, int I, const uint16_t* Bm, int64_t ldb, int J, int K, void* out, int64_t ldo,
+                    int epi) -> int {
+        GemmLaunch g;
+        g.A = (const uint16_t*)A; g.lda = lda; g.I = I; g.B = Bm; g.ldb = ldb; g.J = J; g.K = K;
+        g.out = out; g.ldo = ldo; g.epilogue = epi; g.b_rows_padded = true;
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+        return TVC_OK;
+    };
+    // ---- head: L2 normalise, projection, ln_post (gradient lives on the class rows only)
+    uint16_t* dP16 = (uint16_t*)h->ws[WS_GSMALL].p;                 // [B(+pad), D]
+    uint16_t* dHc = dP16 + ((size_t)B + 256) * D;                   // [B(+pad), d]
+    HIP_TRY(launch_l2norm_bwd((const float*)h->ws[WS_GOUT].p, grad_out_dev, dP16, B, D, h->grad_normalize, st));
+    if ((rc = gemm(h->wT[(size_t)a.layers * 4], D, d, dP16, D, B, D, dHc, d, TVC_EPI_BF16))) return rc;
+    HIP_TRY(hipMemsetAsync(dX, 0, (size_t)rows * d * 4, st));
+    HIP_TRY(hipMemsetAsync(G16, 0, (size_t)rows * d * 2, st));
+    HIP_TRY(launch_layernorm_bwd((const float*)h->ws[WS_GXL].p, d, nullptr, dHc, 0, h->vw.ln_post_g, nullptr, dX, G16, B, d,
+                                 (int64_t)T * d, st));
+    // ---- layers, last to first; the forward of a layer is recomputed from its saved input
+    for (int l = a.layers - 1; l >= 0; --l) {
+        const tvc_layer_weights& w = h->vw.layers[l];
+        void* const* wt = &h->wT[(size_t)l * 4];
+        const float* Xl = saveX + (size_t)l * rows * d;
+        HIP_TRY(hipMemcpyAsync(X, Xl, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
+        // recompute: ln_1, QKV, attention, out-proj (D1), ln_2, FC1 pre-activation (U)
+        HIP_TRY(launch_layernorm(X, d, nullptr, nullptr, 0, w.ln1_g, w.ln1_b, H, (int)rows, d, st));
+        GemmLaunch g;
+        g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
+        g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+        HIP_TRY(launch_attention(QKV, H, nullptr, B, T, a.heads, 0, st));
+        g = GemmLaunch();
+        g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
+        g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+        HIP_TRY(launch_layernorm(X, d, nullptr, D1, 0, w.ln2_g, w.ln2_b, H, (int)rows, d, st));
+        g = GemmLaunch();
+        g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
+        g.bias = w.b1; g.out = U; g.ldo = a.mlp; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+        // MLP branch: dM = dOut W2, dU = dM gelu'(U), dH2 = dU W1, ln_2 backward (+ residual)
+        if ((rc = gemm(wt[3], d, a.mlp, G16, d, (int)rows, d, dM, a.mlp, TVC_EPI_BF16))) return rc;
+        HIP_TRY(launch_gelu_bwd(dM, U, rows * a.mlp, st));
+        if ((rc = gemm(wt[2], a.mlp, d, dM, a.mlp, (int)rows, a.mlp, D2, d, TVC_EPI_BF16))) return rc;
+        HIP_TRY(launch_layernorm_bwd(X, d, D1, D2, 0, w.ln2_g, dX, dX, G16, (int)rows, d, d, st));
+        // attention branch: dAO = dMid Wo, attention backward, dH1 = dQKV Wqkv, ln_1 backward (+ residual)
+        if ((rc = gemm(wt[1], d, d, G16, d, (int)rows, d, H, d, TVC_EPI_BF16))) return rc;
+        HIP_TRY(launch_attention_bwd(QKV, H, dQKV, (float*)h->ws[WS_GSTATS].p, B, T, a.heads, st));
+        if ((rc = gemm(wt[0], 3 * d, d, dQKV, 3 * d, (int)rows, 3 * d, D2, d, TVC_EPI_BF16))) return rc;
+        HIP_TRY(launch_layernorm_bwd(X, d, nullptr, D2, 0, w.ln1_g, dX, dX, G16, (int)rows, d, d, st));
+    }
+    // ---- stem: ln_pre, patch embedding, col2im
+    uint16_t* Pm = (uint16_t*)h->ws[WS_PATCH].p;
+    float* patch_out = (float*)h->ws[WS_GPATCH].p;                  // fp32 [B*P, d], then reused as dcols [B*P, Kp]
+    HIP_TRY(launch_im2col(h->grad_pix, Pm, B, m.image_size, m.patch, Kp, st));
+    if ((rc = gemm(h->vw.patch_w, Kp, d, Pm, Kp, B * P, Kp, patch_out, d, TVC_EPI_F32))) return rc;
+    uint16_t* dpatch = (uint16_t*)h->ws[WS_GDQKV].p;               // bf16 [B*P, d]
+    HIP_TRY(launch_lnpre_bwd(patch_out, h->vw.pos, h->vw.ln_pre_g, dX, dpatch, B, T, d, st));
+    if ((rc = gemm(h->wT[(size_t)a.layers * 4 + 1], d, Kp, dpatch, d, B * P, d, patch_out, Kp, TVC_EPI_F32))) return rc;
+    HIP_TRY(launch_col2im(patch_out, grad_pix_dev, B, m.image_size, m.patch, Kp, st));
+    return TVC_OK;
+}
+
+int tvc_pgd_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const float* grad_dev, float* momentum_dev, int32_t B,
+                 int64_t n, float eps, float alpha, float mu, float clip_min, float clip_max, int32_t targeted, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (B < 0 || n < 0 || (B > 0 && n > 0 && (!adv_dev || !clean_dev || !grad_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_pgd_step: bad arguments");
+    HIP_TRY(launch_pgd_step(adv_dev, clean_dev, grad_dev, momentum_dev, B, n, eps, alpha, mu, clip_min, clip_max, targeted,
+                            (hipStream_t)stream));
+    return TVC_OK;
+}
+
+int tvc_attention_backward(tvc_handle* h, const uint16_t* qkv_dev, const uint16_t* dout_dev, uint16_t* dqkv_dev, int32_t n_seq,
+                           int32_t seq_len, int32_t heads, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!qkv_dev || !dout_dev || !dqkv_dev) return fail(h, TVC_E_INVALID, "tvc_attention_backward: NULL buffer");
+    int rc;
+    if ((rc = ensure(h, WS_GSTATS, (size_t)n_seq * seq_len * heads * 16))) return rc;
+    HIP_TRY(launch_attention_bwd(qkv_dev, dout_dev, dqkv_dev, (float*)h->ws[WS_GSTATS].p, n_seq, seq_len, heads, (hipStream_t)stream));
+    return TVC_OK;
+}
+
+int tvc_layernorm_backward(tvc_handle* h, const float* x_dev, const uint16_t* dy_dev, const float* g_dev, const float* dres_dev,
+                           float* dx_dev, int32_t rows, int32_t d, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!x_dev || !dy_dev || !g_dev || !dx_dev) return fail(h, TVC_E_INVALID, "tvc_layernorm_backward: NULL buffer");
+    HIP_TRY(launch_layernorm_bwd(x_dev, d, nullptr, dy_dev, 0, g_dev, dres_dev, dx_dev, nullptr, rows, d, d, (hipStream_t)stream));
     return TVC_OK;
 }
 

@@ -155,6 +155,51 @@ class TVCEngine:
                                                   int(normalize), _stream()))
         return out
 
+    # ---- input gradient of the vision tower (attacks: PGD / Hubness inner loop) ----------------
+    def encode_image_grad(self, pixels: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """As ``encode_image`` but keeps what ``encode_image_backward`` needs inside the handle.  ``pixels`` must stay
+        alive and unchanged until the backward (the engine holds a reference)."""
+        a = self.arch
+        if pixels.dim() != 4 or pixels.shape[1:] != (3, a.image_size, a.image_size):
+            raise ValueError(f"expected [B, 3, {a.image_size}, {a.image_size}], got {tuple(pixels.shape)}")
+        pixels = _require_cuda(pixels, torch.float32, "pixels")
+        out = torch.empty((pixels.shape[0], a.embed_dim), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_encode_image_grad(self.handle, _ptr(pixels), pixels.shape[0], _ptr(out),
+                                                       int(normalize), _stream()))
+            self._grad_pixels = pixels
+            self._grad_generation = getattr(self, "_grad_generation", 0) + 1
+        return out
+
+    def encode_image_backward(self, grad_out: torch.Tensor, generation: Optional[int] = None) -> torch.Tensor:
+        """d(loss)/d(out of the last ``encode_image_grad``) [B, D] -> d(loss)/d(pixels) [B, 3, S, S]."""
+        px = getattr(self, "_grad_pixels", None)
+        if px is None:
+            raise RuntimeError("encode_image_backward: no encode_image_grad call to differentiate")
+        if generation is not None and generation != self._grad_generation:
+            raise RuntimeError("encode_image_backward: a later encode_image_grad call replaced the saved activations "
+                               "(one differentiable image batch at a time per engine)")
+        grad_out = _require_cuda(grad_out, torch.float32, "grad_out")
+        if tuple(grad_out.shape) != (px.shape[0], self.arch.embed_dim):
+            raise ValueError(f"grad_out must be [{px.shape[0]}, {self.arch.embed_dim}], got {tuple(grad_out.shape)}")
+        gp = torch.empty_like(px)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_encode_image_backward(self.handle, _ptr(grad_out), _ptr(gp), _stream()))
+        return gp
+
+    def pgd_step(self, adv: torch.Tensor, clean: torch.Tensor, grad: torch.Tensor, momentum: Optional[torch.Tensor],
+                 eps: float, alpha: float, mu: float = 0.9, clip_min: float = 0.0, clip_max: float = 1.0,
+                 targeted: bool = False) -> None:
+        """One projected sign-gradient step, in place on ``adv`` (and ``momentum``)."""
+        for name, t in (("adv", adv), ("clean", clean), ("grad", grad), ("momentum", momentum)):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == adv.shape):
+                raise ValueError(f"{name}: contiguous fp32 device tensor shaped like adv expected")
+        B = adv.shape[0]
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_pgd_step(self.handle, _ptr(adv), _ptr(clean), _ptr(grad), _ptr(momentum), B,
+                                              adv.numel() // max(B, 1), eps, alpha, mu, clip_min, clip_max,
+                                              int(targeted), _stream()))
+
     def encode_text(self, tokens: torch.Tensor, normalize: bool = True, group: int = 0) -> torch.Tensor:
         """tokens int [T, ctx] (on the GPU) -> fp32 [T, D].  ``group`` = N + 1 declares that the rows
         are consecutive (original, variant_1 .. variant_N) groups: variants then share the rows of
@@ -378,6 +423,30 @@ class TVCEngine:
             self._check(self.lib.tvc_attention(self.handle, _ptr(qkv), _ptr(out), n_seq, seq_len, heads,
                                                int(causal), _stream()))
         return out
+
+    def attention_backward(self, qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, seq_len: int, heads: int) -> torch.Tensor:
+        qkv = _require_cuda(qkv, torch.bfloat16, "qkv")
+        dout = _require_cuda(dout, torch.bfloat16, "dout")
+        if qkv.shape != (n_seq * seq_len, 3 * heads * 64) or dout.shape != (n_seq * seq_len, heads * 64):
+            raise ValueError("attention_backward: qkv [rows, 3*heads*64] and dout [rows, heads*64] expected")
+        dqkv = torch.empty_like(qkv)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_attention_backward(self.handle, _ptr(qkv), _ptr(dout), _ptr(dqkv), n_seq, seq_len,
+                                                        heads, _stream()))
+        return dqkv
+
+    def layernorm_backward(self, x: torch.Tensor, dy: torch.Tensor, g: torch.Tensor,
+                           dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _require_cuda(x, torch.float32, "x")
+        dy = _require_cuda(dy, torch.bfloat16, "dy")
+        g = _require_cuda(g, torch.float32, "g")
+        if dres is not None:
+            dres = _require_cuda(dres, torch.float32, "dres")
+        dx = torch.empty_like(x)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_layernorm_backward(self.handle, _ptr(x), _ptr(dy), _ptr(g), _ptr(dres), _ptr(dx),
+                                                        x.shape[0], x.shape[1], _stream()))
+        return dx
 
     def layernorm(self, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         x = _require_cuda(x, torch.float32, "x")

@@ -39,8 +39,8 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--model", default="ViT-L/14")
     p.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
     p.add_argument("--variants", type=int, default=8)

@@ -37,7 +37,7 @@ def test_auroc_matches_cpu_oracle(pkg):
     print(f"AUROC oracle {auc_ref:.4f} gpu {auc_gpu:.4f}  max|dscore| {np.abs(got - ref).max():.2e}")
     assert abs(auc_gpu - auc_ref) <= 0.002
     # scores themselves: bf16 towers vs fp32 towers
-    assert np.abs(got - ref).max() < 2e-2
+    assert np.abs(got - ref).max() < 1.5e-3           # measured 5.8e-4
     clip.engine.close()
 
 

@@ -33,8 +33,9 @@ def test_config0_vit_b32_vs_cpu_reference_path(pkg, b32):
     print(f"[measured] ViT-B/32 configs[0] vs oracle (fp32w): image min cos {(fi.cpu() * ri).sum(-1).min().item():.6f} max|d| "
           f"{(fi.cpu() - ri).abs().max().item():.2e}; text min cos {(ft.cpu() * rt).sum(-1).min().item():.6f} max|d| "
           f"{(ft.cpu() - rt).abs().max().item():.2e}")
-    assert (fi.cpu() * ri).sum(-1).min().item() > 0.999
-    assert (ft.cpu() * rt).sum(-1).min().item() > 0.999
+    # bounds ~2x the measured deviation (image 0.999994 / 5.8e-4, text 0.999969 / 1.3e-3); DESIGN.md section 2
+    assert (fi.cpu() * ri).sum(-1).min().item() > 0.99998 and (ft.cpu() * rt).sum(-1).min().item() > 0.99993
+    assert (fi.cpu() - ri).abs().max().item() < 1.2e-3 and (ft.cpu() - rt).abs().max().item() < 2.6e-3
     bank = pkg.synth.plant_neighbours(pkg.synth.make_bank(R, arch.embed_dim, seed=7), rt.reshape(-1, arch.embed_dim), per_anchor=2)
     bank16 = bank.to(torch.bfloat16)
     eng.set_bank(bank16.cuda())
@@ -51,8 +52,8 @@ def test_config0_vit_b32_vs_cpu_reference_path(pkg, b32):
                                   checker=tvc_oracle.ConsistencyCheckerOracle(adaptive_threshold=False))
     print(f"[measured] ViT-B/32 configs[0] end to end: |d score_src| {np.abs(rec[:, 5] - ref['score_src']).max():.2e} "
           f"|d s0| {np.abs(rec[:, 0] - ref['original_similarity']).max():.2e}")
-    assert np.abs(rec[:, 5] - ref["score_src"]).max() < 5e-3
-    assert np.abs(rec[:, 0] - ref["original_similarity"]).max() < 5e-3
+    assert np.abs(rec[:, 5] - ref["score_src"]).max() < 6e-4             # measured 2.6e-4
+    assert np.abs(rec[:, 0] - ref["original_similarity"]).max() < 1.6e-3   # measured 8.1e-4
     assert (same["retrieval_indices"] >= 0).any()
 
 

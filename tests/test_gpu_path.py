@@ -209,7 +209,7 @@ def test_towers_vs_oracle(pkg):
     """Tiny CLIP geometry, shared random weights.  The HIP towers multiply
     bf16-rounded weights and activations with fp32 accumulation; against the
     fp32 oracle on the same bf16-rounded weights the unit-norm embeddings agree
-    to cos > 0.9995 and 2e-2 max-abs (bf16 activations: 2^-9 relative per op)."""
+    within ~2x the deviation measured on MI355X (bf16 activations: 2^-9 relative per op)."""
     arch = pkg.get_arch("ViT-T/16-test")
     vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
     eng = pkg.TVCEngine(arch, vw, tw)
@@ -224,15 +224,14 @@ def test_towers_vs_oracle(pkg):
     assert torch.isfinite(gi).all() and torch.isfinite(gt).all()
     print(f"[measured] ViT-T/16-test vs oracle (bf16w): image min cos {((gi * ri).sum(-1)).min().item():.6f} max|d| "
           f"{(gi - ri).abs().max().item():.2e}; text min cos {((gt * rt).sum(-1)).min().item():.6f} max|d| {(gt - rt).abs().max().item():.2e}")
-    assert ((gi * ri).sum(-1)).min().item() > 0.9995
-    assert ((gt * rt).sum(-1)).min().item() > 0.9995
-    assert (gi - ri).abs().max().item() < 2e-2
-    assert (gt - rt).abs().max().item() < 2e-2
+    # bounds ~2x the measured deviation (image 7.8e-4 / min cos 0.999997, text 1.3e-3 / 0.999989); DESIGN.md section 2
+    assert (gi - ri).abs().max().item() < 1.6e-3 and (gi * ri).sum(-1).min().item() > 0.99999
+    assert (gt - rt).abs().max().item() < 2.6e-3 and (gt * rt).sum(-1).min().item() > 0.99997
     # unnormalised outputs too
     gi2 = eng.encode_image(imgs.cuda(), normalize=False).cpu()
     with torch.no_grad():
         ri2 = clip_oracle.vision_forward(vr, imgs, arch.vision.heads, arch.patch, normalize=False)
-    assert (gi2 - ri2).abs().max().item() < 2e-2 * ri2.abs().max().item()
+    assert (gi2 - ri2).abs().max().item() < 8e-3 * ri2.abs().max().item()
     eng.close()
 
 

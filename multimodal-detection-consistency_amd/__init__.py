@@ -9,7 +9,8 @@ raises ``TVCError``.
 """
 from . import _lib, attacks, sharding, synth
 from ._lib import TVCError, build
-from .attacks import PGDAttackConfig, PGDAttacker, create_pgd_attacker
+from .attacks import (HubnessAttack, HubnessAttackConfig, HubnessAttackPresets, PGDAttackConfig, PGDAttacker,
+                      create_hubness_attacker, create_pgd_attacker)
 from .arch import ARCHS, ClipArch, Tower, get_arch
 from .clip import CLIPConfig, CLIPModel
 from .detector import (AdversarialDetector, ConsistencyChecker, DetectionConfig, DetectorConfig,

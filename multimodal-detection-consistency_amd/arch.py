@@ -65,7 +65,14 @@ ARCHS = {
 }
 
 
+# the names the reference's configs use for the same geometries (src/attacks/hubness_attack.py:43,
+# configs/default.yaml: "openai/clip-vit-base-patch32", "ViT-B/32", "ViT-B-32")
+ALIASES = {"openai/clip-vit-base-patch32": "ViT-B/32", "ViT-B-32": "ViT-B/32", "clip-vit-base-patch32": "ViT-B/32",
+           "openai/clip-vit-large-patch14": "ViT-L/14", "ViT-L-14": "ViT-L/14", "clip-vit-large-patch14": "ViT-L/14"}
+
+
 def get_arch(name: str) -> ClipArch:
+    name = ALIASES.get(name, name)
     try:
         return ARCHS[name]
     except KeyError:

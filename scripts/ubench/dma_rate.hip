@@ -139,6 +139,100 @@ static void run(const char* name, const char* src, size_t bytes_per_wg, int pitc
     hipFree(clk);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gload16_asm(u32x4& dst, const void* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// Split delivery (candidate GEMM form 4): B (tokens) through a 4-slot x 32 KiB LDS ring by LDS-DMA, 3 K-tiles in flight;
+// A (weights) straight into REGISTERS in MFMA operand layout (wave w owns rows w*32 .. w*32+31 of the 256-row tile: no row
+// is needed by two waves): 4 x global_load_dwordx4 per wave and 64-deep K-tile (2 sub-tiles of 16 rows x the two 64-B
+// halves of a line, issued back to back), 3 K-tiles in flight = 48 VGPRs.  One barrier per K-tile.  Nothing is computed.
+template <int ADIRECT>
+__global__ __launch_bounds__(512) void gemm_like2_kernel(const char* __restrict__ src, int pitch, int ktiles, int rounds,
+                                                         unsigned long long* clk, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const size_t tile_bytes = (size_t)256 * pitch;
+    uint32_t vb[4], va[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { const int r = wave * 32 + p * 8 + (lane >> 3); vb[p] = (uint32_t)r * pitch + (lane & 7) * 16; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                 // p = m * 2 + ks
+        const int r = wave * 32 + (p >> 1) * 16 + (lane & 15);
+        va[p] = (uint32_t)r * pitch + (p & 1) * 64 + (lane >> 4) * 16;
+    }
+    const int T = rounds * ktiles;
+    u32x4 A[4][4];
+    unsigned acc = 0;
+    auto src_of = [&](int n, const char*& a, const char*& b) {
+        const int rd = n / ktiles, t = n - rd * ktiles;
+        a = src + (size_t)(j & 3) * tile_bytes + (size_t)t * 128;
+        b = src + (size_t)(4 + ((rd * 8 + xcd) * 8 + (j >> 2))) * tile_bytes + (size_t)t * 128;
+    };
+#define ISSUE(N_, SET_)                                                                                   \
+    if ((N_) < T) {                                                                                       \
+        const char *a_, *b_;                                                                              \
+        src_of((N_), a_, b_);                                                                             \
+        const uint32_t dst = lds + ((N_) & 3) * 32768 + wave * 4096;                                      \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) glds16_asm(b_, vb[p], dst + p * 1024);              \
+        if (ADIRECT) { _Pragma("unroll") for (int p = 0; p < 4; ++p) gload16_asm(A[SET_][p], a_, va[p]); }  \
+        else { _Pragma("unroll") for (int p = 0; p < 4; ++p) glds16_asm(a_, vb[p], lds + 131072 + wave * 4096 + p * 1024); } \
+    }
+#define STEP(I_)                                                                                          \
+    {                                                                                                     \
+        const int n_ = t + (I_);                                                                          \
+        if (n_ < T) {                                                                                     \
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(A[I_][0]), "+v"(A[I_][1]), "+v"(A[I_][2]), "+v"(A[I_][3]) :: "memory"); \
+            __builtin_amdgcn_s_barrier();                                                                 \
+            ISSUE(n_ + 3, ((I_) + 3) & 3)                                                                 \
+            acc += A[I_][0][0] ^ A[I_][1][1] ^ A[I_][2][2] ^ A[I_][3][3];                                 \
+        }                                                                                                 \
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) A[i][p] = u32x4{0u, 0u, 0u, 0u};
+    { const int t = 0; (void)t; ISSUE(0, 0) ISSUE(1, 1) ISSUE(2, 2) }
+    for (int t = 0; t < T; t += 4) { STEP(0) STEP(1) STEP(2) STEP(3) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+    if (acc == 0x12345u) sink[0] = acc;
+#undef STEP
+#undef ISSUE
+}
+
+template <int ADIRECT>
+static void run_gemm_like2(const char* name, const char* src, int pitch, int rounds) {
+    unsigned long long* clk; unsigned* sink;
+    hipMalloc(&clk, 256 * 8); hipMalloc(&sink, 64);
+    const int lds_bytes = ADIRECT ? 131072 : 131072 + 32768;
+    hipFuncSetAttribute((const void*)gemm_like2_kernel<ADIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const int ktiles = pitch / 128;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9;
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(gemm_like2_kernel<ADIRECT>, dim3(256), dim3(512), lds_bytes, 0, src, pitch, ktiles, rounds, clk, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    std::vector<unsigned long long> h(256);
+    hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto c : h) mean += c; mean /= 256;
+    const double bytes = (double)rounds * ktiles * 65536;
+    printf("%-46s %8.3f ms  %6.1f GB/s/CU  %6.2f TB/s  %5.1f B/clk/CU  (%.0f clk/K-tile)\n", name, best, bytes / best / 1e6,
+           bytes * 256 / best / 1e9, bytes / mean, mean / (rounds * ktiles));
+    hipFree(clk); hipFree(sink);
+}
+
 int main() {
     const size_t total = (size_t)2 << 30;                // 2 GiB source: 8 MiB per workgroup
     char* src; hipMalloc(&src, total + (1 << 20)); hipMemset(src, 1, total);
@@ -165,5 +259,10 @@ int main() {
     run_gemm_like("gemm-like, pitch 2048 (K=1024), 8 rounds", src, 2048, 8);
     run_gemm_like("gemm-like, pitch 2176 (padded), 8 rounds", src, 2176, 8);
     run_gemm_like("gemm-like, pitch 2048 (K=1024), 24 rounds", src, 2048, 24);
+    // split delivery: B through a 4 x 32 KiB LDS ring (3 K-tiles in flight), A direct to registers (3 K-tiles in flight)
+    run_gemm_like2<1>("split: B ring 4x32K + A->regs, pitch 8192", src, 8192, 8);
+    run_gemm_like2<1>("split: B ring 4x32K + A->regs, pitch 2048", src, 2048, 8);
+    run_gemm_like2<1>("split: B ring 4x32K + A->regs, pitch 2048 x24", src, 2048, 24);
+    run_gemm_like2<0>("B ring 4x32K + A one LDS buffer (no ring)", src, 8192, 8);
     return 0;
 }

@@ -238,6 +238,12 @@ int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim
 int tvc_cosine_matrix(tvc_handle* h, const float* x_dev, int32_t N, const float* y_dev, int32_t M,
                       int32_t D, float* out_dev, void* stream);
 
+/* Token-level output of the text tower: out fp32 [T, ctx, width] = ln_final(hidden states) at EVERY position
+ * (no pooling, no projection, no EOT packing; causal mask as in tvc_encode_text) -- what a latent-diffusion
+ * pipeline conditions its UNet on (`CLIPTextModel(...).last_hidden_state`; SURVEY.md 8f rank 1: the text encoder of
+ * the SD reference generator, src/sd_ref.py:389-412 via StableDiffusionModel.generate_image). */
+int tvc_encode_text_hidden(tvc_handle* h, const int32_t* tok_dev, int32_t T, float* out_dev, void* stream);
+
 /* ---- input gradient of the vision tower -------- */
 
 /* What `encode_image_tensor(x, requires_grad=True)` + `loss.backward()` give a white-box attack

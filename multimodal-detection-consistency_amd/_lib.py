@@ -93,6 +93,7 @@ SIGNATURES = {
                                 C.c_int32, _P]),
     "tvc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "tvc_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "tvc_encode_text_hidden": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "tvc_encode_image_grad": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "tvc_encode_image_backward": (C.c_int, [_P, _P, _P, _P]),
     "tvc_pgd_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,

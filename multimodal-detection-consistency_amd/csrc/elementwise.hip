@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
                                                         uint16_t* __restrict__ y, int rows, int d,
-                                                        int delta_compact, float* __restrict__ xsum_out) {
+                                                        int delta_compact, float* __restrict__ xsum_out,
+                                                        float* __restrict__ y32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -84,22 +85,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
             f32x4_t o;
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = (v[i][t] - mean) * rstd * gg[t] + bb[t];
-            u32x2_t pk;
-            pk[0] = pack_bf16x2(o[0], o[1]);
-            pk[1] = pack_bf16x2(o[2], o[3]);
-            yr[c] = pk;
+            if (y32) ((f32x4_t*)(y32 + (int64_t)row * d))[c] = o;      // fp32 copy (hidden-state outputs)
+            if (y) {
+                u32x2_t pk;
+                pk[0] = pack_bf16x2(o[0], o[1]);
+                pk[1] = pack_bf16x2(o[2], o[3]);
+                yr[c] = pk;
+            }
         }
     }
 }
 
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
-                            hipStream_t stream, const uint16_t* delta2, int delta_compact, float* xsum_out) {
+                            hipStream_t stream, const uint16_t* delta2, int delta_compact, float* xsum_out, float* y32) {
     if (d % 4 != 0 || d > 1024 || rows < 0) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     const int grid = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, stream, x, x_row_stride, row_idx, delta, delta2,
-                       write_x, g, b, y, rows, d, delta_compact, xsum_out);
+                       write_x, g, b, y, rows, d, delta_compact, xsum_out, y32);
     return hipGetLastError();
 }
 

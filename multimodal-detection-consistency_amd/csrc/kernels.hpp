@@ -32,7 +32,8 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream);
 hipError_t launch_layernorm(float* x, int64_t x_row_stride, const int32_t* row_idx, const uint16_t* delta,
                             int write_x, const float* g, const float* b, uint16_t* y, int rows, int d,
                             hipStream_t stream, const uint16_t* delta2 = nullptr, int delta_compact = 0,
-                            float* xsum_out = nullptr);     // xsum_out: fp32 [rows, d] receives x (+ deltas), compact
+                            float* xsum_out = nullptr,      // xsum_out: fp32 [rows, d] receives x (+ deltas), compact
+                            float* y32 = nullptr);          // y32: fp32 copy of the output rows (y may then be nullptr)
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream);
 hipError_t launch_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,

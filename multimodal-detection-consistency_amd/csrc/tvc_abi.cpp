@@ -451,6 +451,33 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     return TVC_OK;
 }
 
+int tvc_encode_text_hidden(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (!h->has_text) return fail(h, TVC_E_STATE, "tvc_encode_text_hidden: handle has no text tower");
+    if (Tn < 0 || (Tn > 0 && (!tok_dev || !out_dev))) return fail(h, TVC_E_INVALID, "tvc_encode_text_hidden: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_model_desc& m = h->desc;
+    const tvc_tower_arch& a = m.text;
+    const int d = a.width, ctx = m.ctx;
+    if (Tn == 0) return TVC_OK;
+    const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
+    int rc;
+    if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk, WS_TOWER_N))) return rc;
+    if ((rc = ensure(h, WS_EOT, (size_t)chunk * 4))) return rc;
+    for (int t0 = 0; t0 < Tn; t0 += chunk) {
+        const int n = (Tn - t0 < chunk) ? Tn - t0 : chunk;
+        // every position is an output here (the conditioning sequence of a latent-diffusion UNet): dense rows, no
+        // EOT packing, no pooling; the causal mask is the tower's own
+        HIP_TRY(launch_text_embed(tok_dev + (size_t)t0 * ctx, h->tw.tok_emb, h->tw.pos, (float*)h->ws[WS_TX].p,
+                                  (int32_t*)h->ws[WS_EOT].p, nullptr, n, ctx, d, m.vocab, st, nullptr));
+        if ((rc = run_layers(h, a, h->tw.layers, n, ctx, 1, nullptr, 0, WS_TOWER_N, st))) return rc;
+        HIP_TRY(launch_layernorm((float*)h->ws[WS_TX].p, d, nullptr, (const uint16_t*)h->ws[WS_TDELTA].p, 0,
+                                 h->tw.ln_final_g, h->tw.ln_final_b, nullptr, n * ctx, d, st,
+                                 (const uint16_t*)h->ws[WS_TDELTA2].p, 0, nullptr, out_dev + (size_t)t0 * ctx * d));
+    }
+    return TVC_OK;
+}
+
 int tvc_bank_set(tvc_handle* h, const void* bank_dev, int64_t R, int32_t D, int32_t dtype, void* stream) {
     if (!h) return TVC_E_INVALID;
     BankSlot& bk = h->banks[h->cur_bank];

@@ -155,6 +155,18 @@ class TVCEngine:
                                                   int(normalize), _stream()))
         return out
 
+    def encode_text_hidden(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens int [T, ctx] (on the GPU) -> fp32 [T, ctx, width]: ln_final of the hidden state at every position
+        (``CLIPTextModel.last_hidden_state``; the conditioning a latent-diffusion UNet takes)."""
+        a = self.arch
+        if tokens.dim() != 2 or tokens.shape[1] != a.ctx:
+            raise ValueError(f"expected [T, {a.ctx}] tokens, got {tuple(tokens.shape)}")
+        tokens = _require_cuda(tokens, torch.int32, "tokens")
+        out = torch.empty((tokens.shape[0], a.ctx, a.text.width), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_encode_text_hidden(self.handle, _ptr(tokens), tokens.shape[0], _ptr(out), _stream()))
+        return out
+
     # ---- input gradient of the vision tower (attacks: PGD / Hubness inner loop) ----------------
     def encode_image_grad(self, pixels: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         """As ``encode_image`` but keeps what ``encode_image_backward`` needs inside the handle.  ``pixels`` must stay

@@ -101,6 +101,18 @@ def text_forward(w: Dict, tokens: torch.Tensor, heads: int,
     return x
 
 
+def text_hidden(w: Dict, tokens: torch.Tensor, heads: int) -> torch.Tensor:
+    """tokens [B, ctx] int -> [B, ctx, d]: ln_final of the hidden state at every position =
+    ``transformers.CLIPTextModel(...).last_hidden_state`` (the conditioning of the SD UNet; the reference reaches
+    it through the absent ``StableDiffusionModel.generate_image``, /root/reference/src/sd_ref.py:389-412)."""
+    B, T = tokens.shape
+    d = w['tok_emb'].shape[1]
+    x = w['tok_emb'][tokens.long()] + w['pos'][:T]
+    for lw in w['layers']:
+        x = _block(x, lw, heads, causal=True)
+    return F.layer_norm(x, (d,), w['ln_final_g'], w['ln_final_b'], LN_EPS)
+
+
 def round_gemm_weights_to_bf16(w: Dict) -> Dict:
     """Copy of ``w`` whose GEMM operands are rounded to bf16 (and back to fp32),
     the exact values the HIP path multiplies with -- isolates kernel arithmetic

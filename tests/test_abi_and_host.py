@@ -231,3 +231,61 @@ def test_text_variant_rules_follow_the_reference(pkg):
     assert out[:3] == ["a tiny cat", "a little cat", "a mini cat"] and len(out) == 3 + 3 + 10 + 2
     with pytest.raises(ValueError):
         pkg.TextVariantGenerator().generate_variants("a small cat")   # the semantic filter needs a clip_model
+
+
+class _FakeSD:
+    """Stand-in for the absent StableDiffusionModel wrapper: a seeded random image per (prompt, seed)."""
+    def __init__(self):
+        self.calls = []
+
+    def generate_image(self, prompt, num_images, seed, num_inference_steps, guidance_scale, height, width):
+        import torch
+        self.calls.append((prompt, seed, num_inference_steps, guidance_scale, height, width))
+        g = torch.Generator().manual_seed(hash((prompt, seed)) % (2 ** 31))
+        img = torch.rand((3, 64, 64), generator=g)
+        if seed % 5 == 4:
+            img = img * 0.0 + 0.5                              # a blank image: the quality filter must drop it
+        return [img]
+
+    def encode_image(self, image):
+        return image[:, ::8, ::8].numpy()
+
+
+def test_sd_reference_generator_host_logic(pkg):
+    """src/sd_ref.py:342-586 orchestration with an injected diffusion model: prompts x seeds order, fixed seeds,
+    the heuristic quality filter, cache, statistics (the formulas restated here from the reference's lines)."""
+    import numpy as np
+    sd = _FakeSD()
+
+    class Aug:
+        def generate_variants(self, text, methods=None):
+            assert methods == ["synonym", "paraphrase"]
+            return [text + " v1", text + " v2", text + " v3", text + " v4"]
+
+    gen = pkg.SDReferenceGenerator(pkg.SDReferenceConfig(num_images_per_prompt=2, num_text_variants=2), sd_model=sd,
+                                   text_augmenter=Aug())
+    r = gen.generate_reference_images("a cat")
+    # 3 prompts (original + 2 variants) x 2 images, seeds 0..5 in order (:371-377,485-511); seed 4 is blank -> dropped
+    assert [c[:2] for c in sd.calls] == [("a cat", 0), ("a cat", 1), ("a cat v1", 2), ("a cat v1", 3), ("a cat v2", 4), ("a cat v2", 5)]
+    assert sd.calls[0][2:] == (50, 7.5, 512, 512)
+    assert r["seeds"] == [0, 1, 2, 3, 5] and r["num_generated"] == 5 and r["original_prompt"] == "a cat"
+    assert gen.generate_reference_images("a cat") is r and gen.get_stats()["cache_hits"] == 1
+    # quality score formula (:547-586) on one kept image
+    a = r["images"][0].permute(1, 2, 0).numpy() * 255.0
+    want = min(a.std() / 255 * 0.4 + (1 - abs(a.mean() / 255 - 0.5) * 2) * 0.3 + min(np.var(a, axis=(0, 1)).mean() / 1000, 1.0) * 0.3, 1.0)
+    assert abs(gen._assess_image_quality(r["images"][0]) - want) < 1e-6
+    assert gen._assess_image_quality(r["images"][0] * 0 + 0.5) == 0.0
+    # QualityFilter (:87-163)
+    qf = pkg.QualityFilter()
+    m = qf.evaluate_quality(r["images"][0], "a photo of a cat")
+    assert abs(m.clip_score - 5 / 20) < 1e-9 and m.safety_score == 1.0
+    assert abs(m.overall_score - (m.aesthetic_score + m.clip_score + 1.0 + m.technical_score) / 4) < 1e-9
+    assert abs(m.aesthetic_score - min(1.0, (np.var(a) + np.std(a)) / 10000)) < 1e-6
+    # no variants / explicit seeds / random seeds / error path
+    r2 = gen.generate_reference_images("a dog", num_images=1, use_variants=False, seeds=[7])
+    assert r2["seeds"] == [7] and r2["prompts"] == ["a dog"]
+    assert len(gen.generate_reference_vectors("a dog", 1)) == 3          # original + 2 variants, one image each
+    bad = pkg.SDReferenceGenerator(pkg.SDReferenceConfig(), sd_model=None).generate_reference_images("x")
+    assert bad["images"] == [] and "error" in bad
+    assert pkg.GenerationResult([1, 2], ["a", "b"], [0, 1], [pkg.QualityMetrics(overall_score=0.9), pkg.QualityMetrics(overall_score=0.1)]
+                                ).filter_high_quality().images == [1]

@@ -112,3 +112,18 @@ def test_real_vit_b32_geometry_matches_hf():
     assert torch.equal(pv["layers"][11]["wqkv"].float(), vw["layers"][11]["wqkv"].float()) or \
         torch.allclose(pv["layers"][11]["wqkv"].float(), vw["layers"][11]["wqkv"].float(), atol=0)
     assert torch.equal(pt["tok_emb"].float(), tw["tok_emb"].float())
+
+
+def test_text_hidden_states_match_hf_last_hidden_state():
+    """oracle.text_hidden == CLIPTextModel.last_hidden_state at every position (what an SD pipeline feeds its UNet)."""
+    m = _hf()
+    _, tw = clip_oracle.from_hf_state_dict(m.state_dict(), 2, 2)
+    tok = torch.zeros((3, 77), dtype=torch.long)
+    for i, L in enumerate((3, 20, 75)):
+        tok[i, 0] = 49406
+        tok[i, 1:1 + L] = torch.randint(1, 49405, (L,))
+        tok[i, 1 + L:] = 49407                                  # SD pads with the EOT id
+    with torch.no_grad():
+        want = m.text_model(input_ids=tok).last_hidden_state
+        got = clip_oracle.text_hidden(tw, tok, heads=1)
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-4), (got - want).abs().max()

@@ -384,3 +384,25 @@ def test_build_reference_database_roundtrip(pkg, clip, tmp_path):
     assert fi.shape == ft.shape == (300, 128) and ids == list(range(300))
     assert np.abs(fi - direct[:300]).max() < 1e-6
     assert np.abs(ft - clip.encode_text(caps[:300]).numpy()).max() < 1e-6
+
+
+def test_sd_reference_generator_feeds_the_detector(pkg, clip, images):
+    """SURVEY.md 8f rank 1, the orchestration side: SDReferenceGenerator (diffusion model injected) -> batched CLIP
+    encode of the generated references -> the detector's sd_reference score (src/detector.py:524-553)."""
+    from tests.test_abi_and_host import _FakeSD
+    gen = pkg.SDReferenceGenerator(pkg.SDReferenceConfig(num_images_per_prompt=3, use_text_variants=False), sd_model=_FakeSD(),
+                                   clip_model=clip)
+    feats, counts = gen.reference_features(TEXTS[:3])
+    assert counts == [3, 3, 3] and feats.shape == (9, 128) and feats.is_cuda
+    imgs = [im for t in TEXTS[:3] for im in gen.generate_reference_images(t)["images"]]
+    assert torch.equal(feats, clip.engine.encode_image(torch.stack(imgs).cuda(), True))
+    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-T/16-test", num_reference_images=3,
+                                                     detection_methods=["sd_reference", "consistency"]),
+                                  clip_model=clip, sd_generator=gen)
+    res = det.batch_detect(images[:3], TEXTS[:3])
+    fi = clip.encode_image(images[:3]).cpu().numpy()
+    fr = feats.cpu().numpy().reshape(3, 3, -1)
+    for i in range(3):
+        want, _ = O.sd_reference_score([O.cosine(fi[i], f) for f in fr[i]])
+        assert abs(res[i]["detection_scores"]["sd_reference"] - want) < 1e-4
+        assert res[i]["detection_details"]["sd_reference"]["num_references"] == 3

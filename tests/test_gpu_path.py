@@ -494,3 +494,27 @@ def test_pooled_last_layer_is_bit_identical(pkg, model):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     assert torch.equal(out[1][2], out[1][3]) and torch.equal(out[1][2], out[1][4])      # packed == shared == dense
     eng.close()
+
+
+def test_text_hidden_states_vs_oracle(pkg):
+    """tvc_encode_text_hidden: ln_final of every position (CLIPTextModel.last_hidden_state, the SD conditioning).
+    Dense rows, padded with the EOT id as SD does; vs the fp32 oracle on bf16-rounded weights."""
+    arch = pkg.get_arch("ViT-T/16-test")
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, vw, tw)
+    toks = pkg.synth.make_tokens(5, 1, arch.ctx, seed=4).reshape(-1, arch.ctx).clone()
+    eot = toks.argmax(-1)
+    for i in range(toks.shape[0]):
+        toks[i, eot[i]:] = toks[i, eot[i]]
+    got = eng.encode_text_hidden(toks.cuda()).cpu()
+    with torch.no_grad():
+        ref = clip_oracle.text_hidden(clip_oracle.round_gemm_weights_to_bf16(tw), toks.long(), arch.text.heads)
+    assert got.shape == ref.shape == (toks.shape[0], arch.ctx, arch.text.width)
+    err = (got - ref).abs().max().item()
+    print(f"[measured] text hidden states vs oracle (bf16w): max |d| {err:.2e} (|ref| max {ref.abs().max().item():.2f})")
+    assert err < 3e-2 * max(1.0, ref.abs().max().item() / 4)
+    # the pooled EOT row, projected and normalised, is what tvc_encode_text returns
+    emb = eng.encode_text(toks.cuda()).cpu()
+    e2 = torch.nn.functional.normalize(got[torch.arange(toks.shape[0]), eot] @ tw["proj"].float().t(), dim=-1)
+    assert (emb - e2).abs().max().item() < 2e-3
+    eng.close()

@@ -430,11 +430,16 @@ class MultiModalDefenseDetector:
     ``set_reference_bank``)."""
 
     def __init__(self, clip_model: CLIPModel, qwen_model=None, sd_model=None,
-                 config: Optional[DetectionConfig] = None, text_generator=None, retrieval_generator=None):
+                 config: Optional[DetectionConfig] = None, text_generator=None, retrieval_generator=None,
+                 generative_generator=None):
         self.clip_model = clip_model
         self.config = config or DetectionConfig()
         self.text_variant_generator = text_generator if text_generator is not None else qwen_model
         self.retrieval_generator = retrieval_generator
+        # object with generate_references(text) -> list of image tensors (experiments/defenses/generative_ref.py:71);
+        # the diffusion model behind it is not part of this build (SURVEY.md 8f rank 1) -- injected or absent
+        self.generative_generator = generative_generator if generative_generator is not None else (
+            sd_model if hasattr(sd_model, "generate_references") else None)
         # this detector's own bank slot on the (shared) engine; an injected RetrievalReferenceGenerator
         # brings its registered features.npy rows with it
         self.bank_name = getattr(retrieval_generator, "bank_name", None) or f"defense:{id(self):x}"
@@ -512,10 +517,42 @@ class MultiModalDefenseDetector:
                     "text_variant_consistency": vm[j] if N > 0 else s0[j],
                     "text_variant_std": vs[j] if N > 0 else 0.0,
                     "retrieval_consistency": rc[j], "retrieval_std": rs[j],
-                    "generative_consistency": 0.0, "generative_std": 0.0,       # generation out of scope
+                    "generative_consistency": 0.0, "generative_std": 0.0,       # filled below when a generator is injected
                     "cross_modal_variance": xv[j]}
                 k = nref[j]
                 extra[i] = {"retrieval_references": ridx[j][:k], "retrieval_similarities": rsim[j][:k]}
+        # ---- generative references (experiments/defenses/detector.py:206-226,268-280): generated for the first three
+        # of (original + variants), cut to generation_count; ALL of them encoded in one image-tower launch, the
+        # cosines with the query image from the K4 kernel (record words 0, 12..), statistics on the host
+        gen_refs: List[list] = [[] for _ in range(n)]
+        if self.config.use_generative_ref and self.generative_generator is not None:
+            for i in range(n):
+                got: list = []
+                for t in ([texts[i]] + list(variants[i]))[:3]:
+                    got.extend(self.generative_generator.generate_references(t))
+                gen_refs[i] = got[:self.config.generation_count]
+            flat_imgs = [im for g in gen_refs for im in g]
+            if flat_imgs:
+                xr, _ = clip._images_to_device(flat_imgs)
+                fr = eng.encode_image(xr, True)
+                counts = [len(g) for g in gen_refs]
+                offs = np.concatenate([[0], np.cumsum(counts)])
+                by_count: Dict[int, List[int]] = {}
+                for i, c in enumerate(counts):
+                    if c:
+                        by_count.setdefault(c, []).append(i)
+                for J, ids in by_count.items():
+                    rows = torch.as_tensor(np.concatenate([np.arange(offs[i], offs[i] + J) for i in ids]), device=fr.device)
+                    qsel = fi[torch.as_tensor(ids, device=fi.device)].contiguous()
+                    r = eng.consistency(qsel, fr[rows].view(len(ids), J, -1), self._cons_cfg()).cpu().numpy().astype(np.float64)
+                    sims = np.concatenate([r[:, 0:1], r[:, 12:12 + J - 1]], axis=1)
+                    for j, i in enumerate(ids):
+                        pq = per_query[i]
+                        pq["generative_consistency"] = float(sims[j].mean())
+                        pq["generative_std"] = float(sims[j].std())
+                        valid = [v for v in (pq["original_similarity"], pq["text_variant_consistency"],
+                                             pq["retrieval_consistency"], pq["generative_consistency"]) if v > 0]
+                        pq["cross_modal_variance"] = float(np.var(valid)) if len(valid) >= 2 else 0.0     # :295-300
         out = []
         for i in range(n):
             d = self.consistency_checker.make_decision(per_query[i], return_details=return_details)
@@ -525,7 +562,7 @@ class MultiModalDefenseDetector:
                 res["details"] = {"text_variants": [texts[i]] + list(variants[i]),
                                   "retrieval_references": extra[i]["retrieval_references"],
                                   "retrieval_similarities": extra[i]["retrieval_similarities"],
-                                  "generative_references": [], "consistency_scores": per_query[i],
+                                  "generative_references": gen_refs[i], "consistency_scores": per_query[i],
                                   "detection_details": d}
             out.append(res)
         return out
@@ -538,4 +575,4 @@ class MultiModalDefenseDetector:
         return {"config": dict(self.config.__dict__),
                 "components": {"text_variant_generator": self.text_variant_generator is not None,
                                "retrieval_generator": self.clip_model.engine.bank_size(self.bank_name) > 0,
-                               "generative_generator": False, "consistency_checker": True}}
+                               "generative_generator": self.generative_generator is not None, "consistency_checker": True}}

@@ -68,6 +68,7 @@ class TVCEngine:
         self.device = torch.device(device)
         self.arch = arch
         self._lock = threading.Lock()
+        self.dense_fallbacks = 0           # searches that overflowed the candidate lists and were redone brute force
         self._keep = []          # device tensors / ctypes objects referenced by the handle
         # named bank slots: every owner (retriever index, ReferenceBank, defense references ...) registers
         # its rows under its own name, so owners sharing one engine cannot replace each other's bank
@@ -329,7 +330,7 @@ class TVCEngine:
             self._select(bank)
             self._check(self.lib.tvc_bank_search_dense(self.handle, _ptr(rows), rows.shape[0], k, count_thr, idx_offset,
                                                        _ptr(idx), _ptr(sim), _ptr(mom), _stream()))
-        self.dense_fallbacks = getattr(self, "dense_fallbacks", 0) + 1
+        self.dense_fallbacks += 1
         return idx, sim, mom
 
     def bank_status(self) -> None:

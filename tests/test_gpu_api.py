@@ -406,3 +406,43 @@ def test_sd_reference_generator_feeds_the_detector(pkg, clip, images):
         want, _ = O.sd_reference_score([O.cosine(fi[i], f) for f in fr[i]])
         assert abs(res[i]["detection_scores"]["sd_reference"] - want) < 1e-4
         assert res[i]["detection_details"]["sd_reference"]["num_references"] == 3
+
+
+def test_defense_detector_generative_branch(pkg, clip, images):
+    """experiments/defenses/detector.py:206-226,268-300 with an injected generator (the diffusion model itself is
+    not built): references for the first three of (original + variants), cut to generation_count, cos(image, ref)
+    mean / std -> generative_consistency / _std, cross-modal variance over the four means, the checker's decision."""
+    class Gen:
+        def __init__(self):
+            self.asked = []
+
+        def generate_references(self, text):
+            self.asked.append(text)
+            g = torch.Generator().manual_seed(len(text) * 7 + 1)
+            return [torch.randn((3, 64, 64), generator=g) for _ in range(2)]
+
+    gen = Gen()
+    cfg = pkg.DetectionConfig(text_variant_count=3, generation_count=5, use_retrieval_ref=False, adaptive_threshold=False)
+    det = pkg.MultiModalDefenseDetector(clip, config=cfg, generative_generator=gen)
+    got = det.batch_detect(images[:3], TEXTS[:3], return_details=True)
+    assert len(gen.asked) == 9 and gen.asked[0] == TEXTS[0]            # 3 texts per query
+    fi = clip.encode_image(images[:3]).cpu().numpy()
+    ck = O.ConsistencyCheckerOracle(adaptive_threshold=False)
+    for i in range(3):
+        texts_i = got[i]["details"]["text_variants"]
+        ft = clip.encode_text(texts_i).numpy()
+        refs = []
+        for t in texts_i[:3]:
+            g = torch.Generator().manual_seed(len(t) * 7 + 1)
+            refs.extend(torch.randn((3, 64, 64), generator=g) for _ in range(2))
+        refs = refs[:5]
+        assert len(got[i]["details"]["generative_references"]) == 5
+        fr = clip.encode_image(torch.stack(refs).cuda()).cpu().numpy()
+        want = O.compute_consistency_scores_exp(fi[i], ft, None, fr)
+        s = got[i]["details"]["consistency_scores"]
+        for key in ("original_similarity", "text_variant_consistency", "generative_consistency", "generative_std",
+                    "cross_modal_variance"):
+            assert abs(s[key] - want[key]) < 1e-4, (key, s[key], want[key])
+        d = ck.make_decision(want)
+        assert abs(got[i]["consistency_score"] - d["overall_score"]) < 1e-4 and got[i]["is_adversarial"] == d["is_adversarial"]
+    assert det.get_statistics()["components"]["generative_generator"] is True

@@ -518,3 +518,29 @@ def test_text_hidden_states_vs_oracle(pkg):
     e2 = torch.nn.functional.normalize(got[torch.arange(toks.shape[0]), eot] @ tw["proj"].float().t(), dim=-1)
     assert (emb - e2).abs().max().item() < 2e-3
     eng.close()
+
+
+def test_sharded_search_with_a_degenerate_shard(gpu_engine, pkg, tmp_path):
+    """Round-1 advice: a shard whose candidate lists overflow (40 000 identical rows) must not hand the merge a
+    silently truncated list.  ``HipShardOps.search`` goes through ``bank_search_robust``: the overflow is seen
+    (``dense_fallbacks`` counts it) and the shard's answer is the brute-force one -- exact."""
+    import torch.distributed as dist
+    D, M, k, kf = 256, 40, 5, 5
+    row = _unit((1, D), 5)
+    bank = torch.cat([row.repeat(40000, 1), _unit((500, D), 6)]).to(torch.bfloat16).cuda()
+    q = torch.cat([_unit((M - 1, D), 7), row]).cuda()
+    gpu_engine.set_bank(bank)
+    before = getattr(gpu_engine, "dense_fallbacks", 0)
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg2", rank=0, world_size=1)
+    try:
+        s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=bank.shape[0])
+        i, v, f = s.search(q, k, kf)
+    finally:
+        dist.destroy_process_group()
+    assert getattr(gpu_engine, "dense_fallbacks", 0) > before, "the overflow must have been detected"
+    S = q.double() @ bank.double().t()
+    want_v, _ = S.topk(k, dim=1)
+    assert (v.double() - want_v).abs().max().item() < 1e-5
+    # ties (the identical rows) resolve to the smallest indices
+    assert i[M - 1].tolist() == [0, 1, 2, 3, 4]
+    assert torch.equal(f[M - 1, 0].cpu(), bank[0].float().cpu())

@@ -452,7 +452,7 @@ def main():
         out["pgd_inner_loop"] = {"image_steps_per_s": round(pb * ks / d_pgd, 1), "batch": pb, "ms_per_step": round(d_pgd / ks * 1e3, 2),
                                  "gemm_tflops_in_step": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1),
                                  "gemm_gflop_per_image_step": round(fwd_flop / 1e9, 1),
-                                 "note": "forward + per-layer recompute + the four dX GEMMs per layer; no weight gradients"}
+                                 "note": "forward (the backward's inputs are kept, nothing is recomputed) + the four dX GEMMs per layer; no weight gradients"}
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         nq = min(B, 64)

@@ -251,15 +251,17 @@ int tvc_encode_text_hidden(tvc_handle* h, const int32_t* tok_dev, int32_t T, flo
  * the embedding AND d(loss)/d(pixels).  Only the INPUT gradient exists -- the weights are frozen in every
  * attack of the reference -- so no weight-gradient GEMM is ever run.
  *
- * tvc_encode_image_grad: same result as tvc_encode_image (every layer runs over every token; B must fit one
- *   pass, B <= TVC_OPT_MAX_CHUNK_IMAGES) and keeps, inside the handle, each layer's fp32 input rows
- *   (layers * B * T * width * 4 bytes), the un-normalised embedding and the ln_post input.  pix_dev must stay
- *   valid and unchanged until the matching backward (the stem is recomputed from it).
+ * tvc_encode_image_grad: the tower of tvc_encode_image (every layer over every token; the FC1 pre-activation is
+ *   rounded to bf16 before QuickGELU because it is kept: embeddings agree with tvc_encode_image within the tower's
+ *   bf16 tolerance, ~1e-3, not bitwise; B must fit one pass, B <= TVC_OPT_MAX_CHUNK_IMAGES) and KEEPS, inside the handle, what the backward of each layer reads: its
+ *   fp32 input rows, its QKV rows, its out-projection output and the FC1 pre-activation (20 * width bytes per
+ *   token row and layer: 3.9 GB at ViT-L/14 and 32 images), plus the un-normalised embedding and the ln_post
+ *   input.  pix_dev must stay valid and unchanged until the matching backward (the stem is recomputed from it).
  * tvc_encode_image_backward: grad_out fp32 [B, D] = d(loss)/d(out of the LAST tvc_encode_image_grad on this
- *   handle) -> grad_pix fp32 [B, 3, S, S] in the preprocessed (normalised) pixel space.  Each layer's forward is
- *   recomputed from its saved input (activation checkpointing per layer: 2 x the forward's GEMM work once more,
- *   plus 2 x for the four dX GEMMs), gradients travel between GEMMs in bf16 and accumulate along the residual
- *   stream in fp32.  Deterministic (no atomics).  May be called repeatedly for different grad_out. */
+ *   handle) -> grad_pix fp32 [B, 3, S, S] in the preprocessed (normalised) pixel space.  Four dX GEMMs per layer
+ *   (= the forward's GEMM work once more) with fused row kernels between them and a two-pass attention backward;
+ *   nothing of the forward is recomputed.  Gradients travel between GEMMs in bf16 and accumulate along the
+ *   residual stream in fp32.  Deterministic (no atomics).  May be called repeatedly for different grad_out. */
 int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, void* stream);
 int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* grad_pix_dev, void* stream);
 

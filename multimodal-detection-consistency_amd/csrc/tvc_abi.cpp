@@ -165,10 +165,20 @@ size_t pool_bytes(const tvc_tower_arch& a, int n_seq) {
     return (((size_t)n_seq + 256) * a.width * 4 + ((size_t)n_seq + 256) * a.mlp) * 2;
 }
 
+// Input-gradient mode: what the backward of a layer reads is KEPT per layer instead of recomputed (288 GB of HBM:
+// 20 * width bytes per token row and layer -- 3.9 GB at ViT-L/14, 32 images): the layer's fp32 input rows, its QKV
+// rows, its out-projection output (ln_2's second operand) and the FC1 pre-activation.
+struct GradSave {
+    float* x;          // [layers][rows, d]      fp32
+    uint16_t* qkv;     // [layers][rows, 3d]     bf16
+    uint16_t* d1;      // [layers][rows, d]      bf16
+    uint16_t* u;       // [layers][rows, mlp]    bf16
+};
+
 int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* lw, int n_seq, int seq_len,
                int causal, const int32_t* starts, int total_rows, int wso, hipStream_t st,
                const int32_t* pfx = nullptr, int pool_mode = 0, const int32_t* pool_row = nullptr,
-               int64_t pool_x_stride = 0, float* save_x = nullptr) {
+               int64_t pool_x_stride = 0, const GradSave* gs = nullptr) {
     const int d = a.width;
     const int rows = starts ? total_rows : n_seq * seq_len;
     float* X = (float*)h->ws[WS_X + wso].p;
@@ -187,12 +197,17 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
     for (int l = 0; l < a.layers; ++l) {
         const tvc_layer_weights& w = lw[l];
         {
+            // D1 still points at the PREVIOUS layer's out-projection output here
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * (pending ? 14.0 : 6.0));
             HIP_TRY(launch_layernorm(X, d, nullptr, pending ? D1 : nullptr, 1, w.ln1_g, w.ln1_b, H, rows, d, st,
                                      pending ? D2 : nullptr));
         }
-        // input-gradient mode: the residual stream as layer l sees it (X now holds it: ln_1 folded the pending deltas)
-        if (save_x) HIP_TRY(hipMemcpyAsync(save_x + (size_t)l * rows * d, X, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
+        if (gs) {
+            // the residual stream as layer l sees it (X now holds it: ln_1 folded the pending deltas)
+            HIP_TRY(hipMemcpyAsync(gs->x + (size_t)l * rows * d, X, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
+            QKV = gs->qkv + (size_t)l * rows * 3 * d;
+            D1 = gs->d1 + (size_t)l * rows * d;
+        }
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
@@ -236,8 +251,17 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         }
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
-        g.bias = w.b1; g.out = MLP; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16; g.b_rows_padded = true;
-        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+        g.bias = w.b1; g.b_rows_padded = true; g.ldo = a.mlp;
+        if (gs) {
+            // keep the pre-activation (what gelu' needs); the activation is one streaming pass over it
+            uint16_t* U = gs->u + (size_t)l * rows * a.mlp;
+            g.out = U; g.epilogue = TVC_EPI_BF16;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            HIP_TRY(launch_gelu_fwd(U, MLP, (int64_t)rows * a.mlp, st));
+        } else {
+            g.out = MLP; g.epilogue = TVC_EPI_GELU_BF16;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+        }
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
         g.bias = w.b2; g.out = D2; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
@@ -727,7 +751,13 @@ int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float*
     int rc;
     if ((rc = ensure_tower_ws(h, a, rows, B, 0))) return rc;
     if ((rc = ensure(h, WS_PATCH, ((size_t)B * P + 512) * Kp * 2))) return rc;
-    if ((rc = ensure(h, WS_GSAVE, (size_t)a.layers * rows * d * 4))) return rc;
+    const size_t per_layer = (size_t)rows * ((size_t)d * 4 + (size_t)3 * d * 2 + (size_t)d * 2 + (size_t)a.mlp * 2);
+    if ((rc = ensure(h, WS_GSAVE, (size_t)a.layers * per_layer + 256))) return rc;
+    GradSave gs;
+    gs.x = (float*)h->ws[WS_GSAVE].p;
+    gs.qkv = (uint16_t*)(gs.x + (size_t)a.layers * rows * d);
+    gs.d1 = gs.qkv + (size_t)a.layers * rows * 3 * d;
+    gs.u = gs.d1 + (size_t)a.layers * rows * d;
     if ((rc = ensure(h, WS_GOUT, (size_t)B * m.embed_dim * 4))) return rc;
     if ((rc = ensure(h, WS_GXL, (size_t)B * d * 4))) return rc;
     uint16_t* Pm = (uint16_t*)h->ws[WS_PATCH].p;
@@ -739,9 +769,9 @@ int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float*
     g.out = patch_out; g.ldo = d; g.epilogue = TVC_EPI_F32; g.b_rows_padded = true;
     HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
     HIP_TRY(launch_assemble_lnpre(patch_out, h->vw.cls, h->vw.pos, h->vw.ln_pre_g, h->vw.ln_pre_b, (float*)h->ws[WS_X].p, B, T, d, st));
-    if ((rc = run_layers(h, a, h->vw.layers, B, T, 0, nullptr, 0, 0, st, nullptr, 0, nullptr, 0, (float*)h->ws[WS_GSAVE].p))) return rc;
+    if ((rc = run_layers(h, a, h->vw.layers, B, T, 0, nullptr, 0, 0, st, nullptr, 0, nullptr, 0, &gs))) return rc;
     uint16_t* Hc = (uint16_t*)h->ws[WS_CLS].p;
-    HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, (const uint16_t*)h->ws[WS_DELTA].p, 0,
+    HIP_TRY(launch_layernorm((float*)h->ws[WS_X].p, (int64_t)T * d, nullptr, gs.d1 + (size_t)(a.layers - 1) * rows * d, 0,
                              h->vw.ln_post_g, h->vw.ln_post_b, Hc, B, d, st, (const uint16_t*)h->ws[WS_DELTA2].p, 0,
                              (float*)h->ws[WS_GXL].p));
     g = GemmLaunch();
@@ -774,17 +804,12 @@ int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* g
     if ((rc = ensure(h, WS_GSTATS, (size_t)rows * a.heads * 16))) return rc;
     if ((rc = ensure(h, WS_GSMALL, ((size_t)B + 256) * (D + d) * 2))) return rc;
     if ((rc = ensure(h, WS_GPATCH, ((size_t)B * P + 512) * (size_t)(Kp > d ? Kp : d) * 4))) return rc;
-    float* X = (float*)h->ws[WS_X].p;
     uint16_t* H = (uint16_t*)h->ws[WS_H].p;
-    uint16_t* QKV = (uint16_t*)h->ws[WS_QKV].p;
-    uint16_t* U = (uint16_t*)h->ws[WS_MLP].p;
-    uint16_t* D1 = (uint16_t*)h->ws[WS_DELTA].p;
     uint16_t* D2 = (uint16_t*)h->ws[WS_DELTA2].p;
     float* dX = (float*)h->ws[WS_GDX].p;
     uint16_t* G16 = (uint16_t*)h->ws[WS_G16].p;
     uint16_t* dM = (uint16_t*)h->ws[WS_GMLP2].p;
     uint16_t* dQKV = (uint16_t*)h->ws[WS_GDQKV].p;
-    const float* saveX = (const float*)h->ws[WS_GSAVE].p;
     auto gemm = [&](const void* A, int64_t lda, int I, const uint16_t* Bm, int64_t ldb, int J, int K, void* out, int64_t ldo,
                     int epi) -> int {
         GemmLaunch g;
@@ -802,28 +827,18 @@ int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* g
     HIP_TRY(hipMemsetAsync(G16, 0, (size_t)rows * d * 2, st));
     HIP_TRY(launch_layernorm_bwd((const float*)h->ws[WS_GXL].p, d, nullptr, dHc, 0, h->vw.ln_post_g, nullptr, dX, G16, B, d,
                                  (int64_t)T * d, st));
-    // ---- layers, last to first; the forward of a layer is recomputed from its saved input
+    // ---- layers, last to first, on what the forward kept (GradSave)
+    const float* sx = (const float*)h->ws[WS_GSAVE].p;
+    const uint16_t* sqkv = (const uint16_t*)(sx + (size_t)a.layers * rows * d);
+    const uint16_t* sd1 = sqkv + (size_t)a.layers * rows * 3 * d;
+    const uint16_t* su = sd1 + (size_t)a.layers * rows * d;
     for (int l = a.layers - 1; l >= 0; --l) {
         const tvc_layer_weights& w = h->vw.layers[l];
         void* const* wt = &h->wT[(size_t)l * 4];
-        const float* Xl = saveX + (size_t)l * rows * d;
-        HIP_TRY(hipMemcpyAsync(X, Xl, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
-        // recompute: ln_1, QKV, attention, out-proj (D1), ln_2, FC1 pre-activation (U)
-        HIP_TRY(launch_layernorm(X, d, nullptr, nullptr, 0, w.ln1_g, w.ln1_b, H, (int)rows, d, st));
-        GemmLaunch g;
-        g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
-        g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
-        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
-        HIP_TRY(launch_attention(QKV, H, nullptr, B, T, a.heads, 0, st));
-        g = GemmLaunch();
-        g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
-        g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
-        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
-        HIP_TRY(launch_layernorm(X, d, nullptr, D1, 0, w.ln2_g, w.ln2_b, H, (int)rows, d, st));
-        g = GemmLaunch();
-        g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = (int)rows; g.K = d;
-        g.bias = w.b1; g.out = U; g.ldo = a.mlp; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
-        HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
+        const float* X = sx + (size_t)l * rows * d;
+        const uint16_t* QKV = sqkv + (size_t)l * rows * 3 * d;
+        const uint16_t* D1 = sd1 + (size_t)l * rows * d;
+        const uint16_t* U = su + (size_t)l * rows * a.mlp;
         // MLP branch: dM = dOut W2, dU = dM gelu'(U), dH2 = dU W1, ln_2 backward (+ residual)
         if ((rc = gemm(wt[3], d, a.mlp, G16, d, (int)rows, d, dM, a.mlp, TVC_EPI_BF16))) return rc;
         HIP_TRY(launch_gelu_bwd(dM, U, rows * a.mlp, st));

@@ -41,7 +41,7 @@ def test_clip_wrapper_surface(clip, images):
     assert torch.equal(clip.encode_image_tensor(images, requires_grad=False), fi)
     xg = images.clone().requires_grad_(True)                       # the attacks' call (pgd_attack.py:459): autograd reaches the pixels
     fg = clip.encode_image_tensor(xg, requires_grad=True)
-    assert fg.requires_grad and (fg.detach() - fi).abs().max().item() < 2e-6
+    assert fg.requires_grad and (fg.detach() - fi).abs().max().item() < 2e-3     # one more bf16 rounding per MLP (tvc.h)
     fg.sum().backward()
     assert xg.grad is not None and xg.grad.shape == images.shape and torch.isfinite(xg.grad).all() and xg.grad.abs().max() > 0
     from PIL import Image

@@ -331,7 +331,7 @@ def main():
         prof = eng.profile_end()
         g = prof["gemm"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_ring3_kernel<EPI> (all tvc GEMM launches of a step: the persistent ring kernels + the few small gemm_bf16_kernel ones)", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": "gemm_ring4_kernel<EPI> (all tvc GEMM launches of a step: the persistent ring kernels + the few small gemm_bf16_kernel ones)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                 "traffic": None, "launches_per_step": g["launches"],
                 "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}

@@ -663,6 +663,207 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring3_kernel(GemmOperands g
 
 
 // ---------------------------------------------------------------------------
+// Ring main loop, fourth form: barrier-staggered ping-pong in phases of 16 MFMAs (after the "256^2 8-phase"
+// recipe of /opt/skills/guides/cdna_hip_programming.md section 5, rebuilt here for a persistent tile stream).
+//
+//   * A K-tile (64 deep) is multiplied in FOUR phases, one quadrant (64 out-features x 32 tokens x K 64 = 16 MFMAs)
+//     of the wave's 128 x 64 sub-tile each: (Aq0,Bq0) (Aq0,Bq1) (Aq1,Bq1) (Aq1,Bq0).
+//   * A phase is  {LDS reads + ONE half-tile of LDS-DMA}  barrier  {16 MFMAs}  barrier.  The wave group wm = 1 runs one
+//     barrier behind wm = 0, so on every SIMD one wave is in its MFMA segment while its partner is in its load segment:
+//     the matrix pipe never waits for a ds_read, and the LDS-DMA stream is spread evenly (16 KiB per phase).
+//   * LDS: 2 K-tile buffers x (A [256][64] + B [256][64]), the image of form 3.  The STAGING unit is not a contiguous
+//     half but the 128 rows one quadrant reads: Aq = rows {wm*128 + q*64 ..+63}, Bq = rows {wn*64 + q*32 ..+31} over all
+//     waves (16 KiB = 16 pieces, two per wave).  A unit is read in exactly ONE phase (p0: Aq0 + Bq0, p1: Bq1, p2: Aq1;
+//     the fragments then stay in registers, 96 VGPRs), so it is free again two phases later: unit X of K-tile t+2 is
+//     issued 2-3 phases after unit X of K-tile t was read, and FOUR phases (two quadrants' worth of both groups'
+//     MFMAs) before the counted wait that precedes its first read -- s_waitcnt vmcnt(8) in p3 (Aq0, Bq0 of t+1), p0
+//     (Bq1 of t) and p1 (Aq1 of t): four units = 64 KiB always in flight, issued 16 KiB per phase.
+//   * write-after-read: restaged >= 2 phases after the only read.  read-after-write: the counted wait sits before a
+//     phase's first barrier, the read is in the next phase (one barrier more than the wait, because the two groups
+//     are a barrier apart).
+//   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16_rows2_asm(const void* base, uint32_t v0, uint32_t v1, uint32_t lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v0), "v"(v1), "s"(base), "s"(lds)
+                 : "memory", "scc");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kpp = g.ksteps_per_plane;
+    const int nkt = g.planes * kpp;
+
+    RingSchedule sch;
+    sch.init(nIt * nJt);
+    const int my_tiles = sch.count();
+    const int T = my_tiles * nkt;                                  // K-tiles in this workgroup's stream
+    if (T == 0) return;
+
+    const uint32_t smem_lds = lds_addr(smem);
+    struct Cursor { int tile, p, kk; const char* abase; const char* bbase; const char* ap; const char* bp; };
+    auto opaque_lane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto cur_tile = [&](Cursor& c, int lin) __attribute__((always_inline)) {
+        const int jt = lin / nIt;
+        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
+        c.abase = (const char*)(g.A + (int64_t)i0 * g.lda);
+        c.bbase = (const char*)(g.B + (int64_t)j0 * g.ldb);
+        c.ap = c.abase + (int64_t)g.a_plane_off[0] * 2;
+        c.bp = c.bbase + (int64_t)g.b_plane_off[0] * 2;
+    };
+    auto cur_advance = [&](Cursor& c) __attribute__((always_inline)) {
+        c.ap += GEMM_BK * 2; c.bp += GEMM_BK * 2;
+        if (++c.kk == kpp) {
+            c.kk = 0;
+            if (++c.p == g.planes) {
+                c.p = 0;
+                if (++c.tile < my_tiles) cur_tile(c, sch.tile(c.tile));
+            } else {
+                c.ap = c.abase + (int64_t)g.a_plane_off[c.p] * 2;
+                c.bp = c.bbase + (int64_t)g.b_plane_off[c.p] * 2;
+            }
+        }
+    };
+    Cursor is{0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    cur_tile(is, sch.tile(0));
+    // Staging.  Units in stream order per K-tile: Aq0, Bq0, Bq1, Aq1 (issued at phases p2, p3 of K-tile t-2 and p0, p1
+    // of K-tile t-1).  The kind a phase issues is a compile-time constant; the cursor `is` stands on the K-tile being
+    // issued and moves on after its Aq1.  Lane offsets and row offsets are loop constants (4 VGPRs, 4 SGPRs): a load
+    // segment must stay shorter than the partner's 16 MFMAs.
+    const uint32_t pitchA = (uint32_t)(g.lda * 2), pitchB = (uint32_t)(g.ldb * 2);              // bytes per row
+    const int rl = lane >> 3;
+    const uint32_t swz = (uint32_t)(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
+    const uint32_t vA0 = (uint32_t)rl * pitchA + swz, vA1 = (vA0 ^ 64u) + 8u * pitchA;
+    const uint32_t vB0 = (uint32_t)rl * pitchB + swz, vB1 = (vB0 ^ 64u) + 8u * pitchB;
+    // this wave's 16 rows of unit Aq / Bq: 64-row block of wave group (wave >> 2), 32-row block of wave column (wave >> 1)
+    const int rA[2] = {(wave >> 2) * 128 + (wave & 3) * 16, (wave >> 2) * 128 + 64 + (wave & 3) * 16};
+    const int rB[2] = {(wave >> 1) * 64 + (wave & 1) * 16, (wave >> 1) * 64 + 32 + (wave & 1) * 16};
+    int kt_issue = 0;            // K-tile the cursor stands on
+    auto issue_unit = [&](auto kind_c) __attribute__((always_inline)) {
+        constexpr int kind = decltype(kind_c)::value;                  // 0 Aq0, 1 Bq0, 2 Bq1, 3 Aq1
+        constexpr bool isA = (kind == 0 || kind == 3);
+        constexpr int q = (kind >= 2) ? 1 : 0;
+        const int row = isA ? rA[q] : rB[q];
+        const char* base = (isA ? is.ap : is.bp) + (uint32_t)row * (isA ? pitchA : pitchB);
+        const uint32_t dst = smem_lds + (kt_issue & 1) * R3_SLOT_BYTES + (isA ? 0 : GEMM_TILE_BYTES) + row * 128;
+        if (isA) glds16_rows2_asm(base, vA0, vA1, dst); else glds16_rows2_asm(base, vB0, vB1, dst);
+        if (kind == 3) { ++kt_issue; cur_advance(is); }
+    };
+    using U_A0 = std::integral_constant<int, 0>; using U_B0 = std::integral_constant<int, 1>;
+    using U_B1 = std::integral_constant<int, 2>; using U_A1 = std::integral_constant<int, 3>;
+
+    gemm_acc_t acc;
+    gemm_zero_acc(acc);
+    bf16x8_t A0f[4][2], A1f[4][2], B0f[2][2], B1f[2][2];
+    int ct = 0, ckt = 0;
+
+    auto tile_origin = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
+        const int lin = sch.tile(t);
+        const int jt = lin / nIt;
+        i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
+    };
+    typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_p;
+    auto load_A = [&](int t, int q, bf16x8_t (&a)[4][2]) __attribute__((always_inline)) {
+        const int l = opaque_lane();
+        const uint32_t rd = smem_lds + (t & 1) * R3_SLOT_BYTES + (wm * 128 + q * 64 + (l & 15)) * 128 +
+                            (((l >> 4) ^ ((l >> 1) & 7)) * 16);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(lds_frag_p)(uintptr_t)((rd ^ (ks * 64)) + m * 2048);
+    };
+    auto load_B = [&](int t, int q, bf16x8_t (&b)[2][2]) __attribute__((always_inline)) {
+        const int l = opaque_lane();
+        const uint32_t rd = smem_lds + (t & 1) * R3_SLOT_BYTES + GEMM_TILE_BYTES + (wn * 64 + q * 32 + (l & 15)) * 128 +
+                            (((l >> 4) ^ ((l >> 1) & 7)) * 16);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b[n][ks] = *(lds_frag_p)(uintptr_t)((rd ^ (ks * 64)) + n * 2048);
+    };
+#define RING4_MFMA(A_, B_, QA_, QB_)                                                                              \
+    {                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
+                    acc[(QA_) * 4 + m][(QB_) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                        A_[m][ks], B_[n][ks], acc[(QA_) * 4 + m][(QB_) * 2 + n], 0, 0, 0);                        \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    }
+#define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+#define RING4_WAIT8(COND_) { if (COND_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
+    issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
+    if (T >= 2) { issue_unit(U_A0{}); issue_unit(U_B0{}); }
+    RING4_WAIT8(T >= 2)
+    RING4_BARRIER()
+    if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        // ===== p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
+        if (t + 1 < T) issue_unit(U_B1{});
+        load_B(t, 0, B0f);
+        load_A(t, 0, A0f);
+        RING4_WAIT8(t + 1 < T)
+        RING4_BARRIER()
+        RING4_MFMA(A0f, B0f, 0, 0)
+        RING4_BARRIER()
+        // ===== p1: read Bq1; stage Aq1 of K-tile t+1; Aq1 of K-tile t must have landed (read in p2)
+        if (t + 1 < T) issue_unit(U_A1{});
+        load_B(t, 1, B1f);
+        RING4_WAIT8(t + 1 < T)
+        RING4_BARRIER()
+        RING4_MFMA(A0f, B1f, 0, 1)
+        RING4_BARRIER()
+        // ===== p2: read Aq1; stage Aq0 of K-tile t+2 (and the tile's bias slice)
+        if (ckt == 0 && wave == 0 && e.bias) {
+            int i0, j0;
+            tile_origin(ct, i0, j0);
+            if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + R3_LDS_BYTES + (ct & 1) * 1024);
+        }
+        if (t + 2 < T) issue_unit(U_A0{});
+        load_A(t, 1, A1f);
+        RING4_BARRIER()
+        RING4_MFMA(A1f, B1f, 1, 1)
+        RING4_BARRIER()
+        // ===== p3: stage Bq0 of K-tile t+2; Aq0, Bq0 of K-tile t+1 must have landed (read in the next p0)
+        if (t + 2 < T) issue_unit(U_B0{});
+        RING4_WAIT8(t + 2 < T)
+        RING4_BARRIER()
+        RING4_MFMA(A1f, B0f, 1, 0)
+        RING4_BARRIER()
+        if (ckt + 1 == nkt) {
+            int i0, j0;
+            tile_origin(ct, i0, j0);
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
+            gemm_zero_acc(acc);
+            ckt = 0; ++ct;
+        } else {
+            ++ckt;
+        }
+    }
+    if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
+#undef RING4_MFMA
+#undef RING4_BARRIER
+#undef RING4_WAIT8
+}
+
+
+// ---------------------------------------------------------------------------
 // Split-K tail.  A persistent launch over T tiles on 256 workgroups costs ceil(T / 256) rounds; at
 // B = 512 images the ViT-L token count is 514 tile columns, so out-proj / FC2 (4 tile rows) pay a
 // ninth round for 8 tiles (10.8 % of the launch), QKV / FC1 a 25th / 33rd.  The launcher gives the
@@ -736,6 +937,9 @@ static hipError_t set_lds_attr_impl() {
     SET_ATTR(gemm_ring3_kernel<TVC_EPI_F32>)
     SET_ATTR(gemm_ring3_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring3_kernel<TVC_EPI_GELU_BF16>)
+    SET_ATTR(gemm_ring4_kernel<TVC_EPI_F32>)
+    SET_ATTR(gemm_ring4_kernel<TVC_EPI_BF16>)
+    SET_ATTR(gemm_ring4_kernel<TVC_EPI_GELU_BF16>)
     SET_ATTR(gemm_ring2_kernel<TVC_EPI_F32>)
     SET_ATTR(gemm_ring2_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring2_kernel<TVC_EPI_GELU_BF16>)
@@ -822,13 +1026,30 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
             return hipGetLastError();
         }
         const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles / 8) * 8);
-        // ring form: 3 (64-deep K-tiles, whole-line LDS-DMA pieces) where its preconditions hold, else 1;
-        // TVC_GEMM_RING_FORM=1|2|3 forces one (experiments)
-        static const int ring_form = [] { const char* v = getenv("TVC_GEMM_RING_FORM"); return v ? atoi(v) : 3; }();
+        // ring form: 4 (barrier-staggered ping-pong in 16-MFMA phases over 64-deep whole-line K-tiles) where its
+        // preconditions hold (they are form 3's), else 1; TVC_GEMM_RING_FORM=1|2|3|4 forces one (experiments)
+        static const int ring_form = [] { const char* v = getenv("TVC_GEMM_RING_FORM"); return v ? atoi(v) : 4; }();
         // form 3 reads whole rows without clamping: out-feature rows must fill whole tiles, B must have readable
         // rows up to the next multiple of 256 (J % 256 == 0, or a padded workspace: GemmLaunch::b_rows_padded), and
         // the row pitches must be multiples of 128 bytes (its source swizzle flips address bit 6)
-        if (ring_form == 3 && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
+        if (ring_form == 4 && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
+            (L.J % GEMM_BN == 0 || L.b_rows_padded) && L.lda % 64 == 0 && L.ldb % 64 == 0) {
+            switch (L.epilogue) {
+                case TVC_EPI_F32:
+                    hipLaunchKernelGGL(gemm_ring4_kernel<TVC_EPI_F32>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
+                    break;
+                case TVC_EPI_BF16:
+                    hipLaunchKernelGGL(gemm_ring4_kernel<TVC_EPI_BF16>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
+                    break;
+                case TVC_EPI_GELU_BF16:
+                    hipLaunchKernelGGL(gemm_ring4_kernel<TVC_EPI_GELU_BF16>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
+                    break;
+                default:
+                    return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+        if ((ring_form == 3 || ring_form == 4) && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
             (L.J % GEMM_BN == 0 || L.b_rows_padded) && L.lda % 64 == 0 && L.ldb % 64 == 0) {
             switch (L.epilogue) {
                 case TVC_EPI_F32:

@@ -151,7 +151,7 @@ def test_cosine_matrix(gpu_engine, pkg, N, M, D):
 
 
 @pytest.mark.parametrize("env", [{"TVC_GEMM_VARIANT": "2"}, {"TVC_GEMM_SPLITK_TAIL": "1"}, {"TVC_GEMM_SPLITK_SMALL": "1"},
-                                 {"TVC_GEMM_RING_FORM": "1"}, {"TVC_GEMM_RING_FORM": "2"}])
+                                 {"TVC_GEMM_RING_FORM": "1"}, {"TVC_GEMM_RING_FORM": "2"}, {"TVC_GEMM_RING_FORM": "3"}])
 def test_gemm_variants_in_subprocess(env):
     """Env switches read once per process: TVC_GEMM_VARIANT=2 selects gemm_solo_kernel for the
     ring-eligible bf16 GEMMs (incl. a ragged token remainder), TVC_GEMM_SPLITK_TAIL=1 the split-K tail

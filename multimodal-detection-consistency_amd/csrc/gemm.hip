@@ -755,7 +755,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         const int row = isA ? rA[q] : rB[q];
         const char* base = (isA ? is.ap : is.bp) + (uint32_t)row * (isA ? pitchA : pitchB);
         const uint32_t dst = smem_lds + (kt_issue & 1) * R3_SLOT_BYTES + (isA ? 0 : GEMM_TILE_BYTES) + row * 128;
+#ifndef TVC_R4_NO_DMA            // (ablation builds only)
         if (isA) glds16_rows2_asm(base, vA0, vA1, dst); else glds16_rows2_asm(base, vB0, vB1, dst);
+#endif
         if (kind == 3) { ++kt_issue; cur_advance(is); }
     };
     using U_A0 = std::integral_constant<int, 0>; using U_B0 = std::integral_constant<int, 1>;
@@ -790,6 +792,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b[n][ks] = *(lds_frag_p)(uintptr_t)((rd ^ (ks * 64)) + n * 2048);
     };
+#ifdef TVC_R4_NO_MFMA            // (ablation builds only: the fragments are consumed, nothing is multiplied)
+#define RING4_MFMA(A_, B_, QA_, QB_) { _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(A_[m][ks])); _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(B_[n][ks])); }
+#else
 #define RING4_MFMA(A_, B_, QA_, QB_)                                                                              \
     {                                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                            \
@@ -800,6 +805,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
                         A_[m][ks], B_[n][ks], acc[(QA_) * 4 + m][(QB_) * 2 + n], 0, 0, 0);                        \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     }
+#endif
 #define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
 #define RING4_WAIT8(COND_) { if (COND_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

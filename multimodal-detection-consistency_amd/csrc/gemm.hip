@@ -970,7 +970,10 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     static const int forced = [] { const char* v = getenv("TVC_GEMM_VARIANT"); return v ? atoi(v) : -1; }();
     const int ntiles = nIt * nJt;
     const bool deep = (int64_t)L.K * L.planes >= 256;      // >= 8 ring stages per tile
-    const bool ring = deep && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= 512));
+    // (the ring's deep LDS-DMA pipeline also beats the one-tile kernel's wait-per-K-tile loop on launches of fewer
+    // tiles than CUs, one tile per workgroup: TVC_GEMM_RING_MIN_TILES, default 64)
+    static const int ring_min = [] { const char* v = getenv("TVC_GEMM_RING_MIN_TILES"); return v ? atoi(v) : 64; }();
+    const bool ring = deep && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= ring_min));
     // the four-wave kernel takes whole tiles, bf16 outputs and an even stage count; a ragged
     // remainder of token rows is a second launch on the eight-wave kernels
     const bool solo_ok = (L.epilogue == TVC_EPI_BF16 || L.epilogue == TVC_EPI_GELU_BF16) && L.I % GEMM_BM == 0 &&
@@ -1031,7 +1034,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
             }
             return hipGetLastError();
         }
-        const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles / 8) * 8);
+        const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles + 7) / 8 * 8);   // a workgroup without a tile returns at once
         // ring form: 4 (barrier-staggered ping-pong in 16-MFMA phases over 64-deep whole-line K-tiles) where its
         // preconditions hold (they are form 3's), else 1; TVC_GEMM_RING_FORM=1|2|3|4 forces one (experiments)
         static const int ring_form = [] { const char* v = getenv("TVC_GEMM_RING_FORM"); return v ? atoi(v) : 4; }();

@@ -285,7 +285,7 @@ def main():
         rows = torch.cat([fi, ft])                                  # M = B*(N+2) query-side rows
         if a.shard_bank:
             # every rank searches ALL ranks' rows on its shard; partials go back to the rows' owners
-            idx, sim, feat = sharded.search(rows, k, cfg.reference_count)
+            idx, sim, feat = sharded.search(rows, k, cfg.reference_count, feat_from=B)    # image rows need no reference rows
             rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, idx[B:].contiguous(), sim[B:].contiguous(),
                                   feat[B:].contiguous())
             return rec.cpu(), idx[:B].cpu()

@@ -272,6 +272,11 @@ class TVCEngine:
     def has_bank(self, name: str = DEFAULT_BANK) -> bool:
         return name in self._banks
 
+    def bank_is_bf16(self, name: str = DEFAULT_BANK) -> bool:
+        """True when the bank of ``name`` was registered as bf16 (its rows are exact in bf16)."""
+        b = self._banks.get(name)
+        return bool(b and b.get("bf16"))
+
     def set_bank(self, bank: torch.Tensor, name: str = DEFAULT_BANK) -> None:
         """bank [R, D], rows L2-normalised; bf16 is used in place, fp32 is split
         into (hi, lo) bf16 planes inside the handle.  ``name`` = the owner's slot."""
@@ -287,6 +292,7 @@ class TVCEngine:
             if dt == _lib.TVC_DTYPE_F32:
                 torch.cuda.current_stream().synchronize()   # the split read `bank`; it may now be freed
             b["keep"] = bank if dt == _lib.TVC_DTYPE_BF16 else None
+            b["bf16"] = dt == _lib.TVC_DTYPE_BF16
             b["rows"], b["dim"] = bank.shape
 
     def release_bank(self, name: str) -> None:

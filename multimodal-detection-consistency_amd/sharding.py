@@ -20,7 +20,9 @@ Two independent axes:
         distinct peer's slice;
      d. ``tvc_topk_merge`` merges the W sorted partials (HIP kernel).
    With ``rows_per_shard`` given, (c) carries indices + similarities only and two small
-   variable-size all-to-alls (e, f) fetch just the winners' rows from their owners.
+   variable-size all-to-alls (e, f) fetch just the winners' rows from their owners: every DISTINCT
+   winner once (the N+1 text rows of a query mostly retrieve the same references), in bf16 when the
+   bank is bf16 (exact), and none for the image rows of a detection batch (``feat_from``).
    The ``[M, R]`` similarity rows are never exchanged.
 
 The collectives move small tensors; all arithmetic stays in the HIP kernels.
@@ -71,6 +73,11 @@ class HipShardOps:
 
     def gather(self, idx: torch.Tensor):
         return self.engine.bank_gather(idx.contiguous(), idx_offset=self.row_offset)
+
+    @property
+    def transport_dtype(self):
+        """dtype the winners' rows travel in: a bf16 bank's rows are exact in bf16 (half the bytes on the links)."""
+        return torch.bfloat16 if getattr(self.engine, "bank_is_bf16", lambda: False)() else torch.float32
 
     def merge(self, idx_parts, sim_parts, feat_parts):
         idx, sim, feat, _ = self.engine.topk_merge(idx_parts, sim_parts, feat_parts)
@@ -128,9 +135,11 @@ class ShardedBankSearch:
         self.rank = dist.get_rank(group)
         self.rows_per_shard = rows_per_shard
 
-    def search(self, rows: torch.Tensor, k: int, kf: int):
+    def search(self, rows: torch.Tensor, k: int, kf: int, feat_from: int = 0):
         """rows [m, D] (this rank's query-side rows; m equal on every rank) ->
-        idx [m, k] global, sim [m, k], feat [m, kf, D] of the kf best."""
+        idx [m, k] global, sim [m, k], feat [m, kf, D] of the kf best.  ``feat_from``: the first ``feat_from``
+        rows need no feature rows (the image rows of a detection batch: only the text rows' references are
+        compared with the image) -- their feat stays zero and nothing travels for them (two-phase form)."""
         W, (m, D) = self.world, rows.shape
         allrows = torch.empty((W * m, D), dtype=rows.dtype, device=rows.device)
         dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)         # (a)
@@ -146,18 +155,25 @@ class ShardedBankSearch:
             return self.ops.merge(idx_in, sim_in, feat_in)                                # (d)
         # ---- two-phase: merge the lists, then fetch the winners' rows from their owners
         midx, msim, _ = self.ops.merge(idx_in, sim_in, None)                              # (d)
-        win = midx[:, :kf].reshape(-1)                                                    # [m*kf] global, -1 = none
-        owner = torch.where(win >= 0, torch.clamp(win // self.rows_per_shard, max=W - 1), torch.full_like(win, -1))
+        win = midx[feat_from:, :kf].reshape(-1)                                           # global, -1 = none
+        # every DISTINCT winner travels once: the N+1 text rows of a query mostly retrieve the same references
+        uniq, inv = torch.unique(win, return_inverse=True)
+        owner = torch.where(uniq >= 0, torch.clamp(uniq // self.rows_per_shard, max=W - 1), torch.full_like(uniq, -1))
         pos = [torch.nonzero(owner == w).flatten() for w in range(W)]
-        asked = _exchange_lists([win[p_] for p_ in pos], self.group)                      # (e) who wants which of my rows
-        sent = [self.ops.gather(a.view(-1, 1)).view(-1, D) if a.numel() else
-                torch.empty((0, D), dtype=torch.float32, device=rows.device) for a in asked]
+        asked = _exchange_lists([uniq[p_] for p_ in pos], self.group)                     # (e) who wants which of my rows
+        tdt = getattr(self.ops, "transport_dtype", torch.float32)
+        sent = [self.ops.gather(a.view(-1, 1)).view(-1, D).to(tdt) if a.numel() else
+                torch.empty((0, D), dtype=tdt, device=rows.device) for a in asked]
         got = _exchange_lists(sent, self.group)                                           # (f) the rows come back
-        feat = torch.zeros((m * kf, D), dtype=torch.float32, device=rows.device)
+        ufeat = torch.zeros((uniq.numel(), D), dtype=torch.float32, device=rows.device)   # (a -1 entry stays zero)
         for w in range(W):
             if pos[w].numel():
-                feat[pos[w]] = got[w].to(feat.dtype)
-        return midx, msim, feat.view(m, kf, D)
+                ufeat[pos[w]] = got[w].to(torch.float32)
+        feat = torch.zeros((m, kf, D), dtype=torch.float32, device=rows.device)
+        feat[feat_from:] = ufeat[inv].view(m - feat_from, kf, D)
+        self.last_exchange = {"rows_sent": int(sum(t.shape[0] for t in sent)), "distinct_winners": int((uniq >= 0).sum()),
+                              "winner_slots": int(win.numel()), "bytes_per_row": D * (2 if tdt == torch.bfloat16 else 4)}
+        return midx, msim, feat
 
 
 def detect_sharded(engine, search: ShardedBankSearch, img: torch.Tensor, txt: torch.Tensor, cfg) -> torch.Tensor:

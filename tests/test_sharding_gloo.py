@@ -79,8 +79,18 @@ def _worker(rank, world, port, R, D, m, k, kf, out_dir, two_phase):
     lo, hi = pkg.sharding.shard_bounds(R, world, rank)
     per = (R + world - 1) // world
     search = pkg.sharding.ShardedBankSearch(NumpyShardOps(bank[lo:hi], lo), rows_per_shard=per if two_phase else None)
-    mine = torch.from_numpy(q_all[rank * m:(rank + 1) * m])
+    mine = torch.from_numpy(q_all[rank * m:(rank + 1) * m]).clone()
+    mine[m - 1] = mine[m - 2]                      # two query rows with the same winners: each distinct row travels once
     idx, sim, feat = search.search(mine, k, kf)
+    extra = {}
+    if two_phase:
+        ex = search.last_exchange
+        assert ex["distinct_winners"] < ex["winner_slots"], ex
+        # the leading rows of a detection batch (image rows) need no reference rows: nothing travels for them
+        i2, s2, f2 = search.search(mine, k, kf, feat_from=2)
+        assert torch.equal(i2, idx) and torch.equal(s2, sim)
+        assert torch.equal(f2[2:], feat[2:]) and float(f2[:2].abs().max()) == 0.0
+        assert search.last_exchange["winner_slots"] == (m - 2) * kf
     np.savez(Path(out_dir) / f"r{rank}.npz", idx=idx.numpy(), sim=sim.numpy(), feat=feat.numpy(), bank=bank, q=mine.numpy())
     dist.barrier()
     dist.destroy_process_group()

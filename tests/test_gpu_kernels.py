@@ -182,3 +182,23 @@ print("SOLO_OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SOLO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ring_forms_are_bit_identical():
+    """every ring form sums each output element over K in the same order and runs the same epilogue
+    arithmetic, so forms 1, 3 and 4 (the default) return the same BITS on tower-sized launches (incl. QuickGELU, a
+    ragged number of tile rounds, K = 64 and the fp32 epilogue).  scripts/gemm_form_check.py prints a checksum of the
+    raw output bits per shape; the env switch is read once per process, hence the subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = {}
+    for form in ("1", "3", "4"):
+        env = dict(os.environ, TVC_GEMM_RING_FORM=form)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gemm_form_check.py")], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "FORM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        sums[form] = [ln.split("checksum")[1].strip() for ln in r.stdout.splitlines() if "checksum" in ln]
+        assert len(sums[form]) == 8
+    assert sums["1"] == sums["3"] == sums["4"], sums

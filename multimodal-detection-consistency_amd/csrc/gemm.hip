@@ -774,23 +774,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
     };
     typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_p;
+    // Fragment read addresses are loop constants (4 VGPRs; this form has ~50 to spare): a load segment is the
+    // critical path of a slot, so it carries no address arithmetic beyond one add of the buffer offset per K-tile.
+    const uint32_t sw_rd = (uint32_t)((((lane >> 4) ^ ((lane >> 1) & 7)) * 16));
+    const uint32_t a_rd0 = smem_lds + (wm * 128 + (lane & 15)) * 128 + sw_rd, a_rd1 = a_rd0 ^ 64u;                    // k-sub-step 0 / 1
+    const uint32_t b_rd0 = smem_lds + GEMM_TILE_BYTES + (wn * 64 + (lane & 15)) * 128 + sw_rd, b_rd1 = b_rd0 ^ 64u;
     auto load_A = [&](int t, int q, bf16x8_t (&a)[4][2]) __attribute__((always_inline)) {
-        const int l = opaque_lane();
-        const uint32_t rd = smem_lds + (t & 1) * R3_SLOT_BYTES + (wm * 128 + q * 64 + (l & 15)) * 128 +
-                            (((l >> 4) ^ ((l >> 1) & 7)) * 16);
+        const uint32_t po = (uint32_t)(t & 1) * R3_SLOT_BYTES + q * 8192;
+        const uint32_t r0 = a_rd0 + po, r1 = a_rd1 + po;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(lds_frag_p)(uintptr_t)((rd ^ (ks * 64)) + m * 2048);
+        for (int m = 0; m < 4; ++m) {
+            a[m][0] = *(lds_frag_p)(uintptr_t)(r0 + m * 2048);
+            a[m][1] = *(lds_frag_p)(uintptr_t)(r1 + m * 2048);
+        }
     };
     auto load_B = [&](int t, int q, bf16x8_t (&b)[2][2]) __attribute__((always_inline)) {
-        const int l = opaque_lane();
-        const uint32_t rd = smem_lds + (t & 1) * R3_SLOT_BYTES + GEMM_TILE_BYTES + (wn * 64 + q * 32 + (l & 15)) * 128 +
-                            (((l >> 4) ^ ((l >> 1) & 7)) * 16);
+        const uint32_t po = (uint32_t)(t & 1) * R3_SLOT_BYTES + q * 4096;
+        const uint32_t r0 = b_rd0 + po, r1 = b_rd1 + po;
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b[n][ks] = *(lds_frag_p)(uintptr_t)((rd ^ (ks * 64)) + n * 2048);
+        for (int n = 0; n < 2; ++n) {
+            b[n][0] = *(lds_frag_p)(uintptr_t)(r0 + n * 2048);
+            b[n][1] = *(lds_frag_p)(uintptr_t)(r1 + n * 2048);
+        }
     };
 #ifdef TVC_R4_NO_MFMA            // (ablation builds only: the fragments are consumed, nothing is multiplied)
 #define RING4_MFMA(A_, B_, QA_, QB_) { _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(A_[m][ks])); _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(B_[n][ks])); }

@@ -730,7 +730,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
             c.kk = 0;
             if (++c.p == g.planes) {
                 c.p = 0;
-                if (++c.tile < my_tiles) cur_tile(c, sch.tile(c.tile));
+                // past the last tile the stream re-stages the LAST tile's rows (nobody reads them; the stages and
+                // waits of the loop then need no end-of-stream cases: fewer branches in every load segment)
+                cur_tile(c, sch.tile(++c.tile < my_tiles ? c.tile : my_tiles - 1));
             } else {
                 c.ap = c.abase + (int64_t)g.a_plane_off[c.p] * 2;
                 c.bp = c.bbase + (int64_t)g.b_plane_off[c.p] * 2;
@@ -820,25 +822,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
 #define RING4_WAIT8(COND_) { if (COND_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
-    if (T >= 2) { issue_unit(U_A0{}); issue_unit(U_B0{}); }
-    RING4_WAIT8(T >= 2)
+    issue_unit(U_A0{}); issue_unit(U_B0{});
+    RING4_WAIT8(true)
     RING4_BARRIER()
     if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         // ===== p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
-        if (t + 1 < T) issue_unit(U_B1{});
+        issue_unit(U_B1{});
         load_B(t, 0, B0f);
         load_A(t, 0, A0f);
-        RING4_WAIT8(t + 1 < T)
+        RING4_WAIT8(true)
         RING4_BARRIER()
         RING4_MFMA(A0f, B0f, 0, 0)
         RING4_BARRIER()
         // ===== p1: read Bq1; stage Aq1 of K-tile t+1; Aq1 of K-tile t must have landed (read in p2)
-        if (t + 1 < T) issue_unit(U_A1{});
+        issue_unit(U_A1{});
         load_B(t, 1, B1f);
-        RING4_WAIT8(t + 1 < T)
+        RING4_WAIT8(true)
         RING4_BARRIER()
         RING4_MFMA(A0f, B1f, 0, 1)
         RING4_BARRIER()
@@ -848,14 +850,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
             tile_origin(ct, i0, j0);
             if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + R3_LDS_BYTES + (ct & 1) * 1024);
         }
-        if (t + 2 < T) issue_unit(U_A0{});
+        issue_unit(U_A0{});
         load_A(t, 1, A1f);
         RING4_BARRIER()
         RING4_MFMA(A1f, B1f, 1, 1)
         RING4_BARRIER()
         // ===== p3: stage Bq0 of K-tile t+2; Aq0, Bq0 of K-tile t+1 must have landed (read in the next p0)
-        if (t + 2 < T) issue_unit(U_B0{});
-        RING4_WAIT8(t + 2 < T)
+        issue_unit(U_B0{});
+        RING4_WAIT8(true)
         RING4_BARRIER()
         RING4_MFMA(A1f, B0f, 1, 0)
         RING4_BARRIER()
@@ -871,6 +873,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
             ++ckt;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stream's overrun stages must have landed before the LDS is given back
     if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
 #undef RING4_MFMA
 #undef RING4_BARRIER

@@ -41,6 +41,11 @@ extern "C" int tvc_debug_ring_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_stamps), sizeof(ring_stamps));
 }
 __device__ unsigned long long ring_trace[4 * 512];
+// form 4: per wave {first K-tile of a tile, other K-tiles, epilogue issue, barrier after / before the epilogue}
+__device__ unsigned long long ring4_tile_stamps[256 * 8 * 4];
+extern "C" int tvc_debug_ring4_tile_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring4_tile_stamps), sizeof(ring4_tile_stamps));
+}
 extern "C" int tvc_debug_ring_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_trace), sizeof(ring_trace));
 }
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     gemm_acc_t acc;
     gemm_zero_acc(acc);
     bf16x8_t A0f[4][2], A1f[4][2], B0f[2][2], B1f[2][2];
-    int ct = 0, ckt = 0;
+    int ct = 0;
 
     auto tile_origin = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
         const int lin = sch.tile(t);
@@ -827,29 +832,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     RING4_BARRIER()
     if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
 
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
+    // One K-tile.  CREDIT: the number of store instructions the previous tile's epilogue left behind the ring's loads in
+    // this wave's (in-order) vector memory queue: the three counted waits of a tile's first K-tile let them pass
+    // (vmcnt(8 + CREDIT)) instead of draining them; by the next K-tile's first wait (>= 4 phases later) they are the
+    // oldest entries.  It is compile-time: the steady-state body carries neither a compare nor a branch for it, nor for
+    // the tile's bias slice (staged ahead of the previous tile's stores, see below).
+    auto ktile = [&](int t, auto credit_c) __attribute__((always_inline)) {
+        constexpr int CREDIT = decltype(credit_c)::value;
+#define RING4_WAITC() { if (CREDIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+                        else if (CREDIT == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); \
+                        else asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
         // ===== p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
         issue_unit(U_B1{});
         load_B(t, 0, B0f);
         load_A(t, 0, A0f);
-        RING4_WAIT8(true)
+        RING4_WAITC()
         RING4_BARRIER()
         RING4_MFMA(A0f, B0f, 0, 0)
         RING4_BARRIER()
         // ===== p1: read Bq1; stage Aq1 of K-tile t+1; Aq1 of K-tile t must have landed (read in p2)
         issue_unit(U_A1{});
         load_B(t, 1, B1f);
-        RING4_WAIT8(true)
+        RING4_WAITC()
         RING4_BARRIER()
         RING4_MFMA(A0f, B1f, 0, 1)
         RING4_BARRIER()
-        // ===== p2: read Aq1; stage Aq0 of K-tile t+2 (and the tile's bias slice)
-        if (ckt == 0 && wave == 0 && e.bias) {
-            int i0, j0;
-            tile_origin(ct, i0, j0);
-            if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + R3_LDS_BYTES + (ct & 1) * 1024);
-        }
+        // ===== p2: read Aq1; stage Aq0 of K-tile t+2
         issue_unit(U_A0{});
         load_A(t, 1, A1f);
         RING4_BARRIER()
@@ -857,22 +865,78 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         RING4_BARRIER()
         // ===== p3: stage Bq0 of K-tile t+2; Aq0, Bq0 of K-tile t+1 must have landed (read in the next p0)
         issue_unit(U_B0{});
-        RING4_WAIT8(true)
+        RING4_WAITC()
         RING4_BARRIER()
         RING4_MFMA(A1f, B0f, 1, 0)
-        RING4_BARRIER()
-        if (ckt + 1 == nkt) {
+        // (the phase's second barrier is the caller's: at a tile end the two groups place their epilogues differently)
+#undef RING4_WAITC
+    };
+    auto stage_bias = [&](int tile) __attribute__((always_inline)) {
+        if (wave == 0 && e.bias) {
             int i0, j0;
-            tile_origin(ct, i0, j0);
+            tile_origin(tile, i0, j0);
+            if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + R3_LDS_BYTES + (tile & 1) * 1024);
+        }
+    };
+    stage_bias(0);
+    using C0 = std::integral_constant<int, 0>;
+    // stores of a fast epilogue per wave: 16 (16-byte bf16 pieces) or 32 (fp32, or bf16 rows not 16-byte aligned)
+    constexpr int EPI_STORES = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) ? 16 : 32;
+    using CE = std::integral_constant<int, EPI_STORES>;
+    const bool credit_ok = (EPI_STORES == 32) ? ((e.ldo & 3) == 0) : ((e.ldo & 7) == 0);
+    bool credit = false;
+    int t = 0;
+#ifdef TVC_RING_STAMPS
+    unsigned long long ts_first = 0, ts_rest = 0, ts_epi = 0, ts_bar = 0, ts_last = __builtin_amdgcn_s_memtime();
+#define R4T(acc_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - ts_last; ts_last = t_; }
+#else
+#define R4T(acc_)
+#endif
+#pragma unroll 1
+    for (ct = 0; ct < my_tiles; ++ct) {
+        if (credit) ktile(t, CE{}); else ktile(t, C0{});
+        ++t;
+        R4T(ts_first)
+#pragma unroll 1
+        for (int k = 1; k < nkt; ++k, ++t) {
+            RING4_BARRIER()
+            ktile(t, C0{});
+        }
+        R4T(ts_rest)
+        // the NEXT tile's bias slice goes into the queue ahead of this tile's stores: with it there, wave 0's credited
+        // waits ask for one OLDER load more, never for a store
+        if (ct + 1 < my_tiles) stage_bias(ct + 1);
+        int i0, j0;
+        tile_origin(ct, i0, j0);
+        // Tile end.  Group 1 runs its epilogue BEFORE the last phase's second barrier, group 0 after it: group 0 reaches
+        // that barrier a slot earlier, so the two epilogues run side by side (one slot of bias / convert / store latency
+        // per tile instead of two in a row).
+        auto tile_end = [&]() __attribute__((always_inline)) {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
-            gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
-            gemm_zero_acc(acc);
-            ckt = 0; ++ct;
-        } else {
-            ++ckt;
-        }
+#if defined(TVC_R4_NO_EPI)            // (ablation builds only: the sums are consumed, nothing is stored)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(acc[m][n]));
+#else
+            gemm_tile_epilogue<EPI, true, 4, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
+#endif
+        };
+        if (wm == 1) { tile_end(); R4T(ts_epi) }
+        RING4_BARRIER()
+        R4T(ts_bar)
+        if (wm == 0) { tile_end(); R4T(ts_epi) }
+        gemm_zero_acc(acc);
+        credit = credit_ok && (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J);
     }
+#ifdef TVC_RING_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = ring4_tile_stamps + (blockIdx.x * 8 + wave) * 4;
+        o[0] = ts_first; o[1] = ts_rest; o[2] = ts_epi; o[3] = ts_bar;
+    }
+#endif
+#undef R4T
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stream's overrun stages must have landed before the LDS is given back
     if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
 #undef RING4_MFMA

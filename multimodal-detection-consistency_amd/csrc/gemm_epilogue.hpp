@@ -68,8 +68,8 @@ __device__ __forceinline__ void gemm_store4(const GemmEpilogue& e, int I, int i,
 // kernel.  The fast path (tile fully inside the output, aligned rows) contains no
 // exec-masked region and no global load that is not consumed before its end, so hipcc's
 // waitcnt pass sees nothing pending when a persistent caller loops back.
-// NT: 16-token sub-tiles per wave (4: eight-wave kernels, 8: the four-wave kernel).
-template <int EPI, bool BIAS_LDS = false, int NT = 4>
+// NT: 16-token sub-tiles per wave (4: eight-wave kernels, 8: the four-wave kernel).  BIAS_REGS: see below.
+template <int EPI, bool BIAS_LDS = false, int NT = 4, bool BIAS_REGS = false>
 __device__ __forceinline__ void gemm_tile_epilogue(const f32x4_t (&acc)[8][NT], const GemmOperands& g,
                                                    const GemmEpilogue& e, int i0, int j0, int wm, int wn, int lane,
                                                    const char* bias_lds = nullptr) {
@@ -79,13 +79,27 @@ __device__ __forceinline__ void gemm_tile_epilogue(const f32x4_t (&acc)[8][NT], 
                       ((e.ldo & ((NT > 4 && BF16_OUT) ? 7 : 3)) == 0);
     if (fast) {
         const int il = wm * 128 + (lane >> 4) * 4;          // tile-local first out-feature of this lane
-        auto bias_of = [&](int m) -> f32x4_t {
+        auto bias_read = [&](int m) -> f32x4_t {
             if (!e.bias) return f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (BIAS_LDS)
                 return *(const __attribute__((address_space(3))) f32x4_t*)(
                     (const __attribute__((address_space(3))) char*)bias_lds + (il + m * 16) * 4);
             return *(const f32x4_t*)(e.bias + i0 + il + m * 16);
         };
+        // BIAS_REGS (GEMM form 4, whose operand fragments are dead here): the lane's 8 bias vectors are read ONCE, back to
+        // back, into registers.  Left to hipcc, every sub-tile re-reads its vector behind a branch on e.bias and waits
+        // for it -- 32 exposed LDS round trips per wave and tile.  The other forms have no registers to spare.
+        f32x4_t bias_v[BIAS_REGS ? 8 : 1];
+        if (BIAS_REGS) {
+            if (e.bias) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) bias_v[BIAS_REGS ? m : 0] = bias_read(m);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) bias_v[BIAS_REGS ? m : 0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        auto bias_of = [&](int m) -> f32x4_t { return BIAS_REGS ? bias_v[BIAS_REGS ? m : 0] : bias_read(m); };
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int j = j0 + wn * (NT * 16) + n * 16 + (lane & 15);
@@ -126,7 +140,13 @@ __device__ __forceinline__ void gemm_tile_epilogue(const f32x4_t (&acc)[8][NT], 
                     o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                     // (a non-temporal store is 1-3 % faster for this kernel alone and 3.5 % slower for the
                     // layer chain: the next kernel reads these rows back out of L2 / Infinity Cache)
+#ifdef TVC_EPI_NO_STORE                 // (ablation builds only: everything but the store instruction)
+                    asm volatile("" :: "v"(o), "v"(p));
+#elif defined(TVC_EPI_LINEAR_STORE)     // (ablation builds only, WRONG results: every store instruction covers 8 whole lines)
+                    *(u32x4_t*)((uint16_t*)e.out + (int64_t)(j0 + wn * 64 + n * 16 + mp * 4 + (lane >> 4)) * e.ldo + i0 + wm * 128 + (lane & 15) * 8) = o;
+#else
                     *(u32x4_t*)(p + mp * 32) = o;
+#endif
                 }
             } else {
                 uint16_t* p = (uint16_t*)e.out + (int64_t)j * e.ldo + i0 + il;

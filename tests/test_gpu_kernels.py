@@ -77,6 +77,23 @@ def test_gemm_tile_counts_just_above_a_round(gpu_engine, I, J, K, epi):
         assert (out[lo:hi] - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("I,J,K,epi", [(1024, 20000, 64, 1), (512, 40000, 128, 0), (768, 30000, 192, 2)])
+def test_gemm_persistent_without_bias_and_short_k(gpu_engine, I, J, K, epi):
+    """The persistent kernel with bias = nullptr (its epilogue keeps the bias vectors in registers: zeros here) and with
+    one to three K-tiles per output tile (every K-tile is then a tile's FIRST one, whose counted waits let the previous
+    epilogue's stores pass: 16 of them for bf16 outputs, 32 for fp32)."""
+    g = torch.Generator(device="cuda:0").manual_seed(13)
+    a = (torch.randn(I, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(J, K, device="cuda:0", generator=g).to(torch.bfloat16)
+    out = gpu_engine.gemm(a, b, None, epi).float()
+    assert torch.equal(out, gpu_engine.gemm(a, b, None, epi).float())
+    ref = b.float() @ a.float().t()
+    if epi == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    tol = (2e-4 if epi == 0 else 1e-2) * (1 + ref.abs().max().item())
+    assert (out - ref).abs().max().item() < tol
+
+
 def test_gemm_identity_asymmetric(gpu_engine):
     """A = I with an asymmetric B catches a transposed accumulator map."""
     K = 256

@@ -686,6 +686,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring3_kernel(GemmOperands g
 //   * write-after-read: restaged >= 2 phases after the only read.  read-after-write: the counted wait sits before a
 //     phase's first barrier, the read is in the next phase (one barrier more than the wait, because the two groups
 //     are a barrier apart).
+//   * Tile ends.  The K-tile body exists twice: a tile's FIRST K-tile is a copy whose counted waits let the previous
+//     epilogue's stores pass (compile-time vmcnt(8 + stores)); the steady-state copy carries no end-of-tile, bias or
+//     credit test at all.  Group 1 runs its epilogue before the tile's last barrier and group 0 after it, so the two
+//     overlap; the epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
 //   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
 // ---------------------------------------------------------------------------
 // M0 is NOT saved and restored here (two scalar instructions fewer in every load segment, +1-2 %): hipcc generates no

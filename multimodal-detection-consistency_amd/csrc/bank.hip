@@ -30,7 +30,9 @@
 // stored values (|err| ~ 1e-6); an fp32 bank is split the same way and uses the
 // three products hi.hi + lo.hi + hi.lo.
 #include "gemm_core.hpp"
+#include "gemm_ring4.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 #include <mutex>
 
 #define BANK_CAP 128
@@ -350,6 +352,75 @@ __global__ __launch_bounds__(GEMM_THREADS) void bank_search_kernel(GemmOperands 
     }
 }
 
+// The filter pass on GEMM form 4 (gemm_ring4.hpp): the workgroup's bank tiles are ONE stream through the LDS-DMA ring --
+// counted waits, barrier-staggered ping-pong of the two wave groups, the next tile's K-tiles loading while this tile is
+// filtered -- instead of gemm_mainloop's drain-and-barrier per K-tile.  Both operands of this product come out of the L2
+// (a query tile is resident, a bank tile is read by four workgroups for one HBM read), where the CU's request path
+// delivers 2-3 x what it does for first-touch rows, so the loop is bound by the matrix pipe.  Same products, summed in
+// the same order: the listed candidates are identical.  Preconditions (launch_bank_search): the query planes are
+// readable up to the next multiple of 256 rows, row pitches are multiples of 128 bytes; the stream takes the FULL bank
+// tiles, a ragged last tile goes through gemm_mainloop as before.
+__global__ __launch_bounds__(GEMM_THREADS) void bank_filter_ring_kernel(GemmOperands g, BankEpilogue e, int nQt, int S,
+                                                                        int tiles_per_chunk, int n_bank_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds_cnt = (int*)(smem + GEMM_LDS_BYTES);
+    const int lin = xcd_contiguous(blockIdx.x, nQt * S);
+    int qt, chunk;
+    if ((nQt & 3) == 0 && (S & 7) == 0) {       // (the item order of bank_search_kernel)
+        const int blk = lin >> 5, r = lin & 31;
+        const int ncg = S >> 3;
+        const int qg = blk / ncg, cg = blk - qg * ncg;
+        qt = qg * 4 + (r & 3);
+        chunk = cg * 8 + (r >> 2);
+    } else {
+        qt = lin / S; chunk = lin - qt * S;
+    }
+    const int j0 = qt * GEMM_BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    if (threadIdx.x < 256) lds_cnt[threadIdx.x] = 0;
+    float tau[4], sum[4], sq[4], mx[4], cn[4];      // (only tau is live in the filter form)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int q = j0 + wn * 64 + n * 16 + (lane & 15);
+        tau[n] = (q < e.M) ? e.tau[q] : INFINITY;
+        sum[n] = 0.f; sq[n] = 0.f; mx[n] = -INFINITY; cn[n] = 0.f;
+    }
+    __syncthreads();
+
+    const int bt0 = chunk * tiles_per_chunk;
+    int bt1 = bt0 + tiles_per_chunk;
+    if (bt1 > n_bank_tiles) bt1 = n_bank_tiles;
+    const int n_full = (int)(e.R / GEMM_BM);
+    const int bt_ring_end = bt1 < n_full ? bt1 : n_full;
+    ring4_stream(
+        g, smem, bt_ring_end - bt0,
+        [&](int n, int& i0, int& jj0) __attribute__((always_inline)) { i0 = (bt0 + n) * GEMM_BM; jj0 = j0; },
+        [&](int n, const gemm_acc_t& acc) __attribute__((always_inline)) {
+            bank_tile_epilogue<true, true>(acc, e, (int64_t)(bt0 + n) * GEMM_BM, chunk, j0, wm, wn, lane, tau, sum, sq, mx,
+                                           cn, lds_cnt);
+        });
+    for (int bt = (bt_ring_end > bt0 ? bt_ring_end : bt0); bt < bt1; ++bt) {      // the ragged last bank tile
+        gemm_acc_t acc;
+        gemm_zero_acc(acc);
+        const int64_t tile_row0 = (int64_t)bt * GEMM_BM;
+        gemm_mainloop(acc, g, (int)tile_row0, j0, smem);
+        bank_tile_epilogue<false, true>(acc, e, tile_row0, chunk, j0, wm, wn, lane, tau, sum, sq, mx, cn, lds_cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int q = j0 + threadIdx.x;
+        if (q < e.M) {
+            int c = lds_cnt[threadIdx.x];
+            if (c > BANK_CAP) { c = BANK_CAP; atomicOr(e.overflow, 1); }
+            e.cand_cnt[(int64_t)chunk * e.M + q] = c;
+        }
+    }
+}
+
+
 // (v desc, idx asc) ordering
 __device__ __forceinline__ bool cand_better(float v, int idx, float ov, int oidx) {
     return (v > ov) || (v == ov && idx < oidx);
@@ -599,6 +670,9 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
         if (attr_st == hipSuccess)
             attr_st = hipFuncSetAttribute((const void*)bank_search_kernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
+        if (attr_st == hipSuccess)
+            attr_st = hipFuncSetAttribute((const void*)bank_filter_ring_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, BANK_LDS_BYTES);
     });
     if (attr_st != hipSuccess) return attr_st;
     const int D = L.D;
@@ -638,7 +712,14 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     const int nQt = (L.M + GEMM_BN - 1) / GEMM_BN;
     const int nbt = (int)((L.R + GEMM_BM - 1) / GEMM_BM);
     const int tpc = (nbt + L.S - 1) / L.S;
-    if (filter)
+    // the filter pass streams its bank tiles through GEMM form 4 where that form's preconditions hold (TVC_BANK_RING=0:
+    // the one-tile-at-a-time loop, for A/B runs); the ragged last bank tile is handled inside the kernel
+    static const bool ring_on = [] { const char* v = getenv("TVC_BANK_RING"); return !v || atoi(v) != 0; }();
+    const bool ring = filter && ring_on && L.q_rows_padded && (g.lda % 64 == 0) && (g.ldb % 64 == 0) && L.R >= GEMM_BM;
+    if (ring)
+        hipLaunchKernelGGL(bank_filter_ring_kernel, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
+                           g, e, nQt, L.S, tpc, nbt);
+    else if (filter)
         hipLaunchKernelGGL(bank_search_kernel<true>, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
                            g, e, nQt, L.S, tpc, nbt);
     else

@@ -1,6 +1,7 @@
 // Dense bf16 GEMM with fused epilogues for the CLIP towers (K1/K2) and the
 // bank-search pre-pass.  See gemm_core.hpp for the tiling.
 #include "gemm_epilogue.hpp"
+#include "gemm_ring4.hpp"
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -457,8 +458,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring2_kernel(GemmOperands g
 //                      epilogue after the last K-tile of a tile;  no wait, no barrier needed for the ring
 //   K-tile t+2 is in flight during (t, 1) and (t+1, 0): two intervals for 64 KiB.
 // ---------------------------------------------------------------------------
-#define R3_SLOT_BYTES (2 * GEMM_TILE_BYTES)        // 64 KiB
-#define R3_LDS_BYTES (2 * R3_SLOT_BYTES)           // 128 KiB (+ 2 KiB of bias slots)
 
 // four 1-KiB pieces (8 rows x 128 B each) of one operand: one M0 save / restore
 __device__ __forceinline__ void glds16_rows4_asm(const void* base, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3,
@@ -692,21 +691,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring3_kernel(GemmOperands g
 //     overlap; the epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
 //   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
 // ---------------------------------------------------------------------------
-// M0 is NOT saved and restored here (two scalar instructions fewer in every load segment, +1-2 %): hipcc generates no
-// M0 user of its own in gemm_ring4_kernel (gfx950 LDS instructions do not read M0; the only other M0 user, the bias
-// piece, goes through glds16_asm, which saves and restores).  hipcc ignores a clobber of the reserved register -- and
-// says so -- hence the local pragma; tests/test_gpu_kernels.py::test_ring_forms_are_bit_identical guards the result.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void glds16_rows2_asm(const void* base, uint32_t v0, uint32_t v1, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :
-                 : "v"(v0), "v"(v1), "s"(base), "s"(lds)
-                 : "memory", "scc", "m0");
-}
-#pragma clang diagnostic pop
-
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

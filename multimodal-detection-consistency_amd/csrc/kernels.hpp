@@ -77,6 +77,7 @@ struct BankSearchLaunch {
     const float* rows = nullptr;      // [M, D] the fp32 query rows (exact re-scoring of the fast form)
     const float* bank_bounds = nullptr;// [2] device: max |hi plane row|, max |lo plane row|
     bool allow_filter = true;         // one-product filter + re-scoring when no moments are requested
+    bool q_rows_padded = false;       // qplanes is readable up to the next multiple of 256 rows (the ring-form filter pass)
     int M = 0;
     int k = 0;
     float count_thr = 0.f;

@@ -556,7 +556,7 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     BankSearchLaunch L;
     bank_plan(bk.R, M, k, &L.n_sample, &L.sample_stride, &L.S, &L.cap);
     int rc;
-    if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
+    if ((rc = ensure(h, WS_QPLANES, (size_t)((M + 255) / 256 * 256) * 2 * D * 2))) return rc;
     if ((rc = ensure(h, WS_S0, (size_t)M * L.n_sample * 4))) return rc;
     if ((rc = ensure(h, WS_TAU, (size_t)M * 4))) return rc;
     if ((rc = ensure(h, WS_CAND, (size_t)L.S * M * L.cap * 8))) return rc;
@@ -565,7 +565,7 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     if ((rc = ensure(h, WS_OVERFLOW, 16))) return rc;
     HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
     L.bank = bk.bank; L.ldb = (int64_t)bk.planes * D; L.R = bk.R; L.D = D; L.bank_planes = bk.planes;
-    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
+    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.q_rows_padded = true; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
     L.rows = rows_dev; L.bank_bounds = bk.bounds; L.allow_filter = h->bank_filter;
     L.s0 = (float*)h->ws[WS_S0].p; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
@@ -597,12 +597,12 @@ int tvc_bank_search_dense(tvc_handle* h, const float* rows_dev, int32_t M, int32
     if (block > 64) block = 64;
     if (block < 1) block = 1;
     int rc;
-    if ((rc = ensure(h, WS_QPLANES, (size_t)M * 2 * D * 2))) return rc;
+    if ((rc = ensure(h, WS_QPLANES, (size_t)((M + 255) / 256 * 256) * 2 * D * 2))) return rc;
     if ((rc = ensure(h, WS_S0, (size_t)block * bk.R * 4))) return rc;
     HIP_TRY(launch_split_planes(rows_dev, (uint16_t*)h->ws[WS_QPLANES].p, M, D, 2, st));
     BankSearchLaunch L;
     L.bank = bk.bank; L.ldb = (int64_t)bk.planes * D; L.R = bk.R; L.D = D; L.bank_planes = bk.planes;
-    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.M = M; L.k = k; L.count_thr = count_thr;
+    L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.q_rows_padded = true; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
     HIP_TRY(launch_bank_search_dense(L, (float*)h->ws[WS_S0].p, block, st));

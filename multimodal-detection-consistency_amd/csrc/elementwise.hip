@@ -6,6 +6,13 @@
 #include "kernels.hpp"
 
 #define LN_EPS 1e-5f
+// Non-temporal hints of the LayerNorm pass (bit mask: 1 = x loads, 2 = x stores, 4 = delta loads, 8 = y stores).  The
+// residual stream and the projection output are read ONCE here and re-read only after the next GEMMs have streamed
+// > 256 MB through the caches, so they are marked streaming: 7 measured 14.0 -> 12.6 ms of LayerNorm per step against 0
+// (13.0 with 5, 13.1 with 15: the normalised rows ARE re-read, by the next GEMM, and stay cacheable).
+#ifndef TVC_LN_NT
+#define TVC_LN_NT 7
+#endif
 #define ROWS_PER_BLOCK 4   // 256 threads = 4 waves = 4 rows
 
 // ---------------------------------------------------------------------------
@@ -41,9 +48,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
         const int c = lane + i * 64;
         v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
+#if TVC_LN_NT & 1
+            v[i] = __builtin_nontemporal_load(xr + c);
+#else
             v[i] = xr[c];
+#endif
             if (dr) {
+#if TVC_LN_NT & 4
+                const u32x2_t dd = __builtin_nontemporal_load(dr + c);
+#else
                 const u32x2_t dd = dr[c];
+#endif
                 v[i][0] += __uint_as_float(dd[0] << 16);
                 v[i][1] += __uint_as_float(dd[0] & 0xffff0000u);
                 v[i][2] += __uint_as_float(dd[1] << 16);
@@ -56,7 +71,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                 v[i][2] += __uint_as_float(dd[1] << 16);
                 v[i][3] += __uint_as_float(dd[1] & 0xffff0000u);
             }
+#if TVC_LN_NT & 2
+            if (write_x && (dr || dr2)) __builtin_nontemporal_store(v[i], xr + c);
+#else
             if (write_x && (dr || dr2)) xr[c] = v[i];
+#endif
             if (xsum_out) ((f32x4_t*)(xsum_out + (int64_t)row * d))[c] = v[i];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -90,7 +109,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
                 u32x2_t pk;
                 pk[0] = pack_bf16x2(o[0], o[1]);
                 pk[1] = pack_bf16x2(o[2], o[3]);
+#if TVC_LN_NT & 8
+                __builtin_nontemporal_store(pk, yr + c);
+#else
                 yr[c] = pk;
+#endif
             }
         }
     }

@@ -33,6 +33,26 @@
 // NW: waves per workgroup.  4 everywhere: a 6-wave form for the 257-token vision case (17 query
 // blocks in 3 rounds instead of 5) needs 3 waves per SIMD = 168 VGPRs, spills 94 of them and runs
 // 3.5x slower (1201 vs 343 us) - the 17 score tiles of a query block want the 256-register budget.
+// Non-temporal hints (bit mask: 1 = K / V loads, 2 = Q loads, 4 = output stores): every 128-byte line of the packed QKV
+// rows is read by exactly one workgroup, once.
+#ifndef TVC_ATT_NT
+#define TVC_ATT_NT 3      // measured 9.17 -> 9.08 ms of attention per step (7: 9.26, the out-projection re-reads the output)
+#endif
+#if TVC_ATT_NT & 1
+#define ATT_LD_KV(p_) __builtin_nontemporal_load(p_)
+#else
+#define ATT_LD_KV(p_) (*(p_))
+#endif
+#if TVC_ATT_NT & 2
+#define ATT_LD_Q(p_) __builtin_nontemporal_load(p_)
+#else
+#define ATT_LD_Q(p_) (*(p_))
+#endif
+#if TVC_ATT_NT & 4
+#define ATT_ST_O(p_, v_) __builtin_nontemporal_store(v_, p_)
+#else
+#define ATT_ST_O(p_, v_) (*(p_) = (v_))
+#endif
 template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16_t* __restrict__ qkv,
                                                         uint16_t* __restrict__ out,
@@ -92,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
             kv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) kv[i] = *(const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8);
+            if (key < T) kv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8));
         }
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
             vv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) vv[i] = *(const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8);
+            if (key < T) vv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8));
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
@@ -149,12 +169,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         return qkv + (row0 + qrow) * ld + h * ATT_DH + 8 * g;
     };
     bf16x8_t nq0 = {}, nq1 = {};
-    if (wsub < NQ) { const uint16_t* qp = q_ptr(wsub); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
+    if (wsub < NQ) { const uint16_t* qp = q_ptr(wsub); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
 
     for (int qb = wsub; qb < NQ; qb += WPS) {
         const int qr = qb * 16 + r16;
         const bf16x8_t bq0 = nq0, bq1 = nq1;
-        if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = *(const bf16x8_t*)qp; nq1 = *(const bf16x8_t*)(qp + 32); }
+        if (qb + WPS < NQ) { const uint16_t* qp = q_ptr(qb + WPS); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
         // absolute positions of the block's first / last query and of this lane's query
         const int qmin = pool_mode ? pool_pos : P + qb * 16;
         const int qmax = pool_mode ? pool_pos : qmin + 15;
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 u32x2_t w;
                 w[0] = pack_bf16x2(o[md][0] * inv, o[md][1] * inv);
                 w[1] = pack_bf16x2(o[md][2] * inv, o[md][3] * inv);
-                *(u32x2_t*)(op + md * 16) = w;
+                ATT_ST_O((u32x2_t*)(op + md * 16), w);
             }
         }
     }

@@ -812,11 +812,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
 #endif
 #define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
-#define RING4_WAIT8(COND_) { if (COND_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define RING4_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
     issue_unit(U_A0{}); issue_unit(U_B0{});
-    RING4_WAIT8(true)
+    RING4_WAIT8()
     RING4_BARRIER()
     if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
 

@@ -100,46 +100,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     const int64_t ld = 3 * (int64_t)width;
     const int tsub = wsub * 64 + lane;     // thread index within the item's waves
 
-    // ---- fill K / V images (zero beyond T).  All global loads of an image are issued before
-    // the first LDS write, so the workgroup pays ONE memory latency per image, not one per piece.
-    constexpr int STEP = WPS * 64;
-    constexpr int KIT = (MAXT * 16 * 8 + STEP - 1) / STEP;
-    constexpr int VIT = (((MAXT + 1) / 2) * 32 * 8 + STEP - 1) / STEP;
-    {
-        u32x4_t kv[KIT];
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int idx = tsub + i * STEP;
-            const int key = idx >> 3, c = idx & 7;
-            kv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) kv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8));
-        }
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int idx = tsub + i * STEP;
-            const int key = idx >> 3, c = idx & 7;
-            if (idx < KT * 8) *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = kv[i];
-        }
-    }
-    {
-        u32x4_t vv[VIT];
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int idx = tsub + i * STEP;
-            const int key = idx >> 3, c = idx & 7;
-            vv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) vv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8));
-        }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int idx = tsub + i * STEP;
-            const int key = idx >> 3, c = idx & 7;
-            if (idx < VT * 8) *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = vv[i];
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-
     const int g = lane >> 4, r16 = lane & 15;
     const int sw0 = ((0 + g) ^ ((lane >> 1) & 7)) << 4;
     const int sw1 = ((4 + g) ^ ((lane >> 1) & 7)) << 4;
@@ -170,6 +130,44 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     };
     bf16x8_t nq0 = {}, nq1 = {};
     if (wsub < NQ) { const uint16_t* qp = q_ptr(wsub); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
+
+    // ---- fill K / V images (zero beyond T).  ALL global loads of the item -- both images and the first query block --
+    // are issued before the first LDS write, so the workgroup pays ONE memory latency per item (K and V used to be
+    // filled one after the other: two).
+    constexpr int STEP = WPS * 64;
+    constexpr int KIT = (MAXT * 16 * 8 + STEP - 1) / STEP;
+    constexpr int VIT = (((MAXT + 1) / 2) * 32 * 8 + STEP - 1) / STEP;
+    {
+        u32x4_t kv[KIT], vv[VIT];
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            kv[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (key < T) kv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            vv[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (key < T) vv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8));
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            if (idx < KT * 8) *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = kv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int idx = tsub + i * STEP;
+            const int key = idx >> 3, c = idx & 7;
+            if (idx < VT * 8) *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = vv[i];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
 
     for (int qb = wsub; qb < NQ; qb += WPS) {
         const int qr = qb * 16 + r16;

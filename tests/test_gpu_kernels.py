@@ -219,3 +219,37 @@ def test_ring_forms_are_bit_identical():
         sums[form] = [ln.split("checksum")[1].strip() for ln in r.stdout.splitlines() if "checksum" in ln]
         assert len(sums[form]) == 8
     assert sums["1"] == sums["3"] == sums["4"], sums
+
+
+def test_bank_filter_ring_and_one_tile_loops_agree():
+    """The filter pass of the bank search on GEMM form 4 (default) and on the one-tile-at-a-time loop (TVC_BANK_RING=0)
+    sum the same products in the same order: identical top-k indices and similarities, for a ragged bank (R % 256 != 0),
+    a ragged query count (padded query rows of the workspace are read but never listed) and both bank dtypes."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch, tvc_amd as pkg
+eng = pkg.TVCEngine()
+g = torch.Generator(device="cuda:0").manual_seed(5)
+for R, M, D, k, dt in ((70001, 300, 768, 5, torch.bfloat16), (33000, 512, 512, 10, torch.float32), (4096, 17, 1024, 3, torch.bfloat16)):
+    bank = torch.nn.functional.normalize(torch.randn(R, D, device="cuda:0", generator=g), dim=-1).to(dt)
+    q = torch.nn.functional.normalize(torch.randn(M, D, device="cuda:0", generator=g), dim=-1)
+    eng.set_bank(bank)
+    idx, sim = eng.bank_search(q, k, want_moments=False)[:2]        # no moments: the filter form
+    ref = (q.double() @ bank.double().t()).topk(k, dim=1)
+    if dt == torch.bfloat16:          # exact products; an fp32 bank's near-ties may order differently in fp64
+        assert torch.equal(idx.long().cpu(), ref.indices.cpu()), (R, M, D)
+    assert (sim.double().cpu() - ref.values.cpu()).abs().max().item() < 2e-6, (R, M, D)
+    print("TOPK", R, M, int(idx.long().sum().item()), sim.cpu().numpy().tobytes().hex()[:64], float(sim.double().sum().item()).hex())
+print("BANK_OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for ring in ("1", "0"):
+        env = dict(os.environ, TVC_BANK_RING=ring)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "BANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[ring] = [ln for ln in r.stdout.splitlines() if ln.startswith("TOPK")]
+        assert len(outs[ring]) == 3
+    assert outs["1"] == outs["0"], outs

@@ -224,7 +224,8 @@ def test_ring_forms_are_bit_identical():
 def test_bank_filter_ring_and_one_tile_loops_agree():
     """The filter pass of the bank search on GEMM form 4 (default) and on the one-tile-at-a-time loop (TVC_BANK_RING=0)
     sum the same products in the same order: identical top-k indices and similarities, for a ragged bank (R % 256 != 0),
-    a ragged query count (padded query rows of the workspace are read but never listed) and both bank dtypes."""
+    a ragged query count (padded query rows of the workspace are read but never listed), both bank dtypes, and one / two
+    K-tiles per bank tile (D = 64, 128)."""
     import os
     import subprocess
     import sys
@@ -232,7 +233,8 @@ def test_bank_filter_ring_and_one_tile_loops_agree():
 import torch, tvc_amd as pkg
 eng = pkg.TVCEngine()
 g = torch.Generator(device="cuda:0").manual_seed(5)
-for R, M, D, k, dt in ((70001, 300, 768, 5, torch.bfloat16), (33000, 512, 512, 10, torch.float32), (4096, 17, 1024, 3, torch.bfloat16)):
+for R, M, D, k, dt in ((70001, 300, 768, 5, torch.bfloat16), (33000, 512, 512, 10, torch.float32), (4096, 17, 1024, 3, torch.bfloat16),
+                       (5000, 40, 64, 4, torch.bfloat16), (2500, 260, 128, 2, torch.float32)):
     bank = torch.nn.functional.normalize(torch.randn(R, D, device="cuda:0", generator=g), dim=-1).to(dt)
     q = torch.nn.functional.normalize(torch.randn(M, D, device="cuda:0", generator=g), dim=-1)
     eng.set_bank(bank)
@@ -251,5 +253,5 @@ print("BANK_OK")
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "BANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         outs[ring] = [ln for ln in r.stdout.splitlines() if ln.startswith("TOPK")]
-        assert len(outs[ring]) == 3
+        assert len(outs[ring]) == 5
     assert outs["1"] == outs["0"], outs

@@ -171,10 +171,51 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
     }
 }
 
+// The same through LDS: one workgroup per (image, patch row).  The 3 * patch image rows of that patch row are read as whole
+// rows (S floats contiguous: coalesced), converted and scattered into the LDS image of the g output rows, which are then
+// written as whole rows (Kp * 2 bytes contiguous).  The per-element kernel above reads 56-byte runs (patch 14) with one
+// scalar load per element: 1.75 TB/s against ~4.5 here.  S % 4 == 0 and g * Kp * 2 bytes of LDS (<= 64 KiB) required.
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ pix, uint16_t* __restrict__ out,
+                                                          int S, int patch, int Kp) {
+    extern __shared__ __attribute__((aligned(16))) char im_smem[];
+    uint16_t* tile = (uint16_t*)im_smem;               // [g][Kp]
+    const int g = S / patch;
+    const int bimg = blockIdx.x / g, py = blockIdx.x - bimg * g;
+    const int K = 3 * patch * patch;
+    // zero the padding columns
+    for (int i = threadIdx.x; i < g * (Kp - K); i += 256) {
+        const int px = i / (Kp - K), c = K + (i - px * (Kp - K));
+        tile[px * Kp + c] = 0;
+    }
+    const int s4 = S >> 2;                              // float4 per image row
+    const int total = 3 * patch * s4;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int rowi = i / s4, x4 = i - rowi * s4;    // rowi = c * patch + ky
+        const int c = rowi / patch, ky = rowi - c * patch;
+        const f32x4_t v = __builtin_nontemporal_load(
+            (const f32x4_t*)(pix + (((int64_t)bimg * 3 + c) * S + (py * patch + ky)) * S) + x4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = x4 * 4 + e;
+            const int px = x / patch, kx = x - px * patch;
+            tile[px * Kp + c * patch * patch + ky * patch + kx] = f32_to_bf16_bits(v[e]);
+        }
+    }
+    __syncthreads();
+    const int chunks = (g * Kp) >> 3;                   // 16-byte pieces of the g contiguous output rows
+    u32x4_t* dst = (u32x4_t*)(out + ((int64_t)bimg * g * g + (int64_t)py * g) * Kp);
+    for (int i = threadIdx.x; i < chunks; i += 256) dst[i] = ((const u32x4_t*)tile)[i];
+}
+
 hipError_t launch_im2col(const float* pix, uint16_t* out, int B, int image, int patch, int Kp,
                          hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     const int g = image / patch;
+    const size_t lds = (size_t)g * Kp * 2;
+    if (image % 4 == 0 && Kp % 8 == 0 && lds <= 64 * 1024) {
+        hipLaunchKernelGGL(im2col_rows_kernel, dim3(B * g), dim3(256), lds, stream, pix, out, image, patch, Kp);
+        return hipGetLastError();
+    }
     const int64_t total = (int64_t)B * g * g * (Kp >> 3);
     int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;

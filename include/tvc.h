@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TVC_ABI_VERSION 2
+#define TVC_ABI_VERSION 3
 #define TVC_MAX_BANKS 8      /* bank slots per handle (tvc_bank_select)          */
 #define TVC_MAX_TOPK 128     /* largest k of tvc_bank_search / tvc_topk_merge    */
 
@@ -97,6 +97,33 @@ typedef struct {
     const tvc_layer_weights* layers;   /* HOST array of `text.layers` structs              */
 } tvc_text_weights;
 
+/* fp32 copies of the same weights for the fp32-grade tower mode (TVC_OPT_TOWER_PRECISION): identical field order,
+ * every tensor fp32, nothing rounded to bf16.  patch_w is the UNPADDED conv weight [d, 3*patch*patch]. */
+typedef struct {
+    const float* ln1_g;  const float* ln1_b;
+    const float* wqkv;   const float* bqkv;
+    const float* wo;     const float* bo;
+    const float* ln2_g;  const float* ln2_b;
+    const float* w1;     const float* b1;
+    const float* w2;     const float* b2;
+} tvc_layer_weights_f32;
+
+typedef struct {
+    const float* patch_w;      /* fp32 [d, 3*patch*patch], columns ordered (c, ky, kx) */
+    const float* cls;  const float* pos;
+    const float* ln_pre_g;  const float* ln_pre_b;
+    const float* ln_post_g; const float* ln_post_b;
+    const float* proj;         /* fp32 [D, d] */
+    const tvc_layer_weights_f32* layers;   /* HOST array of `vision.layers` structs */
+} tvc_vision_weights_f32;
+
+typedef struct {
+    const float* tok_emb;  const float* pos;
+    const float* ln_final_g; const float* ln_final_b;
+    const float* proj;         /* fp32 [D, d] */
+    const tvc_layer_weights_f32* layers;   /* HOST array of `text.layers` structs */
+} tvc_text_weights_f32;
+
 /* ---- lifetime -------------------------------------------------------- */
 
 uint32_t tvc_abi_version(void);
@@ -139,10 +166,23 @@ const char* tvc_last_error(tvc_handle* h);
  * in their LAST layer only that token's attention output, out-projection, ln_2 and MLP are ever read.  With the
  * option on, those are computed for the pooled rows only (K and V still come from every token): the embeddings
  * are unchanged (same fp32 sums in the same order) while 10/12 of the last layer's GEMM work is not done.  0 runs
- * the last layer over every token like the others. */
+ * the last layer over every token like the others.
+ * TVC_OPT_TOWER_PRECISION (default 0): 0 = the towers multiply bf16 x bf16 on the MFMA units with fp32 accumulation
+ * (the benchmarked path: embeddings within ~1e-3 of an fp32 CPU tower).  1 = fp32-grade towers: tvc_encode_image /
+ * tvc_encode_text / tvc_encode_text_hidden run every GEMM on the exact-f32 matrix instruction (v_mfma_f32_32x32x2_f32)
+ * with the fp32 weights registered by tvc_set_weights_f32, fp32 activations and fp32 attention -- embeddings within
+ * ~1e-6 of the reference's fp32 CPU path (src/detector.py:461-485; configs/attacks/pgd.yaml:80 asks for fp32), so the
+ * consistency scores meet the 1e-4 bar END TO END.  About 10x slower; validation and attack-generation mode, never the
+ * benchmarked one.  Needs tvc_set_weights_f32 first (TVC_E_STATE otherwise).  The input-gradient entry points
+ * (tvc_encode_image_grad / _backward) always run the bf16 path. */
 enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
-       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6 };
+       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6, TVC_OPT_TOWER_PRECISION = 7 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
+
+/* Register fp32 copies of the tower weights for TVC_OPT_TOWER_PRECISION = 1 (either may be NULL).  Referenced, not
+ * copied: the caller keeps the buffers alive.  Geometry = the desc given to tvc_create.
+ * Replaces: loading the fp32 checkpoint in the (absent) src.models CLIPModel -- src/detector.py:258-271. */
+int tvc_set_weights_f32(tvc_handle* h, const tvc_vision_weights_f32* vision, const tvc_text_weights_f32* text);
 
 /* Bytes of device workspace currently held by the handle. */
 uint64_t tvc_workspace_bytes(tvc_handle* h);
@@ -357,6 +397,15 @@ int tvc_attention_backward(tvc_handle* h, const uint16_t* qkv_dev, const uint16_
  * dres fp32 [rows, d] or NULL (added: the residual path's gradient), dx fp32 [rows, d]. */
 int tvc_layernorm_backward(tvc_handle* h, const float* x_dev, const uint16_t* dy_dev, const float* g_dev,
                            const float* dres_dev, float* dx_dev, int32_t rows, int32_t d, void* stream);
+
+/* Building blocks of the fp32-grade tower mode (TVC_OPT_TOWER_PRECISION = 1), exported for parity tests:
+ * out[j, i] (op)= sum_k x[j, k] * w[i, k] + bias[i] on the exact-f32 matrix instruction; w fp32 [I, K], x fp32 [J, K],
+ * out fp32 [J, ld_out]; K % 4 == 0; epilogue 0 = store, 1 = QuickGELU, 2 = out += (residual add). */
+int tvc_gemm_f32(tvc_handle* h, const float* w_dev, const float* x_dev, const float* bias_dev, float* out_dev,
+                 int32_t I, int32_t J, int32_t K, int32_t ld_out, int32_t epilogue, void* stream);
+/* fp32 multi-head attention, head_dim 64, seq_len <= 288: qkv fp32 [n_seq * seq_len, 3 * width], out fp32 [rows, width]. */
+int tvc_attention_f32(tvc_handle* h, const float* qkv_dev, float* out_dev, int32_t n_seq, int32_t seq_len,
+                      int32_t heads, int32_t causal, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,7 @@ class CLIPConfig:
     #                                       file holding a transformers.CLIPModel state dict
     seed: int = 0
     tokenizer_dir: Optional[str] = None   # directory with CLIP BPE vocab.json + merges.txt
+    precision: str = "bf16"               # "fp32": fp32-grade towers (the reference's fp32 path to ~1e-6; ~10x slower)
 
 
 class HashTokenizer:
@@ -161,7 +162,8 @@ class CLIPModel:
             else:
                 from safetensors.torch import load_file
                 weights = weights_from_hf_state_dict(load_file(self.config.weights), self.arch)
-        self.engine = TVCEngine(self.arch, weights[0], weights[1], device=str(self.device))
+        self.engine = TVCEngine(self.arch, weights[0], weights[1], device=str(self.device),
+                                precision=self.config.precision)
         self.tokenizer = (BPETokenizer(self.config.tokenizer_dir, self.arch.ctx) if self.config.tokenizer_dir
                           else HashTokenizer(self.arch.ctx))
         self.model = self          # `.model` is handed to nn.DataParallel by attacks (out of scope)

@@ -135,3 +135,12 @@ hipError_t launch_pgd_step(float* adv, const float* clean, const float* grad, fl
                            float alpha, float mu, float lo, float hi, int targeted, hipStream_t stream);
 hipError_t launch_attention_bwd(const uint16_t* qkv, const uint16_t* dao, uint16_t* dqkv, float* stats_ws, int n_seq, int T,
                                 int heads, hipStream_t stream);
+
+// ---- precise.hip: fp32-grade towers (exact-f32 MFMA GEMM, fp32 attention)
+// out[j, i] (op)= sum_k X[j, k] W[i, k] + bias[i]; epi 0 store, 1 QuickGELU, 2 out += ; K, ldw, ldx multiples of 4
+hipError_t launch_gemm_f32(const float* W, int64_t ldw, const float* X, int64_t ldx, const float* bias, float* out,
+                           int64_t ldo, int I, int J, int K, int epi, hipStream_t stream);
+hipError_t launch_attention_f32(const float* qkv, float* out, int n_seq, int T, int heads, int causal, hipStream_t stream);
+hipError_t launch_im2col_f32(const float* pix, float* out, int B, int image, int patch, hipStream_t stream);
+hipError_t launch_gather_f32_rows(const float* x, int64_t ld, const int32_t* idx, int64_t idx_mul, float* out, int n,
+                                  int d, hipStream_t stream);

@@ -2,143 +2,14 @@
 // sequences of the CLIP towers, the bank search and the consistency kernel.
 // No torch types, no exceptions across the boundary, no device synchronisation
 // except where tvc.h says so.
-#include "../../include/tvc.h"
-#include "kernels.hpp"
+#include "handle.hpp"
 
-#include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
+// tvc_precise.cpp
+int tvc_precise_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, hipStream_t st);
+int tvc_precise_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, int32_t normalize,
+                            float* hidden_out, hipStream_t st);
 
 namespace {
-
-thread_local std::string g_create_error;
-
-enum Slot {
-    // tower workspaces exist twice (vision, text: + WS_TOWER_N) so that the two towers can run
-    // concurrently on two streams
-    WS_X = 0, WS_H, WS_QKV, WS_MLP, WS_CLS, WS_DELTA, WS_DELTA2, WS_SPLITK, WS_POOL, WS_TOWER_N,
-    WS_TX = WS_TOWER_N, WS_TH, WS_TQKV, WS_TMLP, WS_TCLS, WS_TDELTA, WS_TDELTA2, WS_TSPLITK, WS_TPOOL,
-    WS_PATCH, WS_EOT, WS_STARTS, WS_PFX, WS_LENS,
-    WS_COSX, WS_COSY, WS_COSXP, WS_COSYP,
-    WS_QPLANES, WS_S0, WS_TAU, WS_CAND, WS_CAND_CNT, WS_MOM_PART, WS_OVERFLOW,
-    // input-gradient path (vision tower): saved layer inputs, gradient stream, scratch
-    WS_GSAVE, WS_GOUT, WS_GXL, WS_GDX, WS_G16, WS_GMLP2, WS_GDQKV, WS_GSTATS, WS_GSMALL, WS_GPATCH,
-    WS_COUNT
-};
-
-struct Buf {
-    void* p = nullptr;
-    size_t n = 0;
-};
-
-struct BankSlot {
-    const uint16_t* bank = nullptr;
-    void* owned = nullptr;            // (hi | lo) planes of an fp32 bank
-    int64_t R = 0;
-    int D = 0;
-    int planes = 1;
-    float* bounds = nullptr;          // device [2]: max row norms of the bank planes
-};
-
-struct ProfRec {
-    hipEvent_t a, b;
-    int cat;
-    double work;
-};
-
-}  // namespace
-
-struct tvc_handle {
-    tvc_model_desc desc{};
-    bool has_vision = false, has_text = false;
-    tvc_vision_weights vw{};
-    tvc_text_weights tw{};
-    std::vector<tvc_layer_weights> vlayers, tlayers;
-    // banks: TVC_MAX_BANKS independent slots (retriever index, reference bank, defense references ...
-    // registered by different owners on one engine); tvc_bank_select picks the one the bank calls address
-    BankSlot banks[TVC_MAX_BANKS];
-    int cur_bank = 0;
-    bool bank_filter = true;          // TVC_OPT_BANK_FILTER
-    Buf ws[WS_COUNT];
-    std::string err;
-    int max_chunk_images = 512;
-    int max_chunk_texts = 4608;
-    bool pack_text = true;     // TVC_OPT_TEXT_PACKING
-    int text_group = 0;        // TVC_OPT_TEXT_GROUP: texts come in groups of this many sharing prefixes (0: off)
-    bool pooled_last = true;   // TVC_OPT_POOLED_LAST_LAYER
-    // input-gradient state: transposed GEMM weights (built on first use), what the last tvc_encode_image_grad saw
-    std::vector<void*> wT;     // per layer: wqkvT, woT, w1T, w2T; then projT, patchT
-    int grad_B = 0;
-    int grad_normalize = 0;
-    const float* grad_pix = nullptr;
-    bool prof = false;
-    std::vector<ProfRec> prof_recs;
-};
-
-namespace {
-
-int fail(tvc_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_create_error = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t st__ = (expr);                                                            \
-        if (st__ != hipSuccess)                                                              \
-            return fail(h, TVC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(st__));  \
-    } while (0)
-
-int ensure(tvc_handle* h, Slot s, size_t bytes) {
-    Buf& b = h->ws[s];
-    if (b.n >= bytes && b.p) return TVC_OK;
-    if (b.p) {
-        // hipFree synchronises the device, so kernels still using the old block are done
-        if (hipFree(b.p) != hipSuccess) return fail(h, TVC_E_HIP, "hipFree(workspace) failed");
-        b.p = nullptr; b.n = 0;
-    }
-    // grow with a little slack so alternating sizes do not thrash
-    const size_t want = bytes + bytes / 16 + 256;
-    if (hipMalloc(&b.p, want) != hipSuccess) {
-        b.p = nullptr;
-        char m[128];
-        snprintf(m, sizeof m, "workspace allocation of %zu bytes failed", want);
-        return fail(h, TVC_E_NOMEM, m);
-    }
-    b.n = want;
-    return TVC_OK;
-}
-
-// RAII bracket: two events around whatever is launched inside the scope
-struct ProfScope {
-    tvc_handle* h; hipStream_t st; ProfRec r; bool on;
-    ProfScope(tvc_handle* h_, hipStream_t st_, int cat, double work) : h(h_), st(st_), on(h_->prof) {
-        if (!on) return;
-        r.cat = cat; r.work = work;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(r.a, st);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        (void)hipEventRecord(r.b, st);
-        h->prof_recs.push_back(r);
-    }
-};
-
-double gemm_flops(const GemmLaunch& g) { return 2.0 * g.I * (double)g.J * g.K * g.planes; }
-
-hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st, int splitk_slot = -1) {
-    ProfScope ps(h, st, TVC_PROF_GEMM, gemm_flops(g));
-    if (splitk_slot >= 0 && h->ws[splitk_slot].p) {
-        GemmLaunch g2 = g;
-        g2.splitk_ws = (float*)h->ws[splitk_slot].p;
-        g2.splitk_ws_bytes = h->ws[splitk_slot].n;
-        return launch_gemm_bf16(g2, st);
-    }
-    return launch_gemm_bf16(g, st);
-}
 
 bool tower_ok(const tvc_tower_arch& a) {
     return a.width > 0 && a.layers > 0 && a.heads > 0 && a.width == a.heads * 64 && a.width % 64 == 0 &&
@@ -341,6 +212,7 @@ int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision, con
 
 void tvc_destroy(tvc_handle* h) {
     if (!h) return;
+    tvc_sd_free(h);
     for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
     for (void* p : h->wT) if (p) (void)hipFree(p);
     for (auto& bk : h->banks) {
@@ -369,6 +241,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
     const int Kp = (3 * m.patch * m.patch + 63) / 64 * 64;
     const int chunk = B < h->max_chunk_images ? B : h->max_chunk_images;
     if (B == 0) return TVC_OK;
+    if (h->tower_precision == 1) return tvc_precise_encode_image(h, pix_dev, B, out_dev, normalize, st);
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk, 0))) return rc;
     if ((rc = ensure(h, WS_PATCH, ((size_t)chunk * P + 512) * Kp * 2))) return rc;      // + tile padding, as ensure_tower_ws
@@ -418,6 +291,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     const tvc_tower_arch& a = m.text;
     const int d = a.width, ctx = m.ctx;
     if (Tn == 0) return TVC_OK;
+    if (h->tower_precision == 1) return tvc_precise_encode_text(h, tok_dev, Tn, out_dev, normalize, nullptr, st);
     int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
     // prefix sharing needs whole groups in a pass
     const int G = (h->pack_text && h->text_group >= 2 && Tn % h->text_group == 0) ? h->text_group : 0;
@@ -484,6 +358,7 @@ int tvc_encode_text_hidden(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, fl
     const tvc_tower_arch& a = m.text;
     const int d = a.width, ctx = m.ctx;
     if (Tn == 0) return TVC_OK;
+    if (h->tower_precision == 1) return tvc_precise_encode_text(h, tok_dev, Tn, nullptr, 0, out_dev, st);
     const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk, WS_TOWER_N))) return rc;
@@ -896,6 +771,11 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
         case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
         case TVC_OPT_BANK_FILTER: h->bank_filter = value != 0; return TVC_OK;
         case TVC_OPT_POOLED_LAST_LAYER: h->pooled_last = value != 0; return TVC_OK;
+        case TVC_OPT_TOWER_PRECISION:
+            if (value != 0 && value != 1) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TOWER_PRECISION must be 0 (bf16) or 1 (fp32)");
+            if (value == 1 && !h->has_vision32 && !h->has_text32)
+                return fail(h, TVC_E_STATE, "tvc_set_option: TVC_OPT_TOWER_PRECISION = 1 needs tvc_set_weights_f32 first");
+            h->tower_precision = (int)value; return TVC_OK;
         case TVC_OPT_TEXT_GROUP:
             if (value < 0 || value > 4096) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TEXT_GROUP out of range");
             h->text_group = (int)value; return TVC_OK;

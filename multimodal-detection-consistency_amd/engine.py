@@ -61,7 +61,7 @@ class TVCEngine:
     """Owns a ``tvc_handle`` and the device copies of the tower weights."""
 
     def __init__(self, arch: Optional[ClipArch] = None, vision_w: Optional[Dict] = None,
-                 text_w: Optional[Dict] = None, device: str = "cuda:0"):
+                 text_w: Optional[Dict] = None, device: str = "cuda:0", precision: str = "bf16"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.TVCError(_lib.TVC_E_HIP, "no GPU visible to PyTorch-ROCm; the TVC path has no CPU fallback")
@@ -88,8 +88,55 @@ class TVCEngine:
                                      C.byref(vis) if vis is not None else None,
                                      C.byref(txt) if txt is not None else None, C.byref(self.handle))
             _lib.check(None, rc)
+        self._w_host = (vision_w, text_w)     # the caller's (fp32) weight dicts: the fp32-grade mode uploads them as they are
+        self._has_f32 = False
+        self.precision = "bf16"
+        if precision != "bf16":
+            self.set_precision(precision)
 
     # ---- weights -------------------------------------------------------
+    def _layers_f32(self, layers) -> "C.Array":
+        arr = (_lib.LayerWeights * len(layers))()
+        for i, lw in enumerate(layers):
+            for name in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2"):
+                setattr(arr[i], name, self._dev(lw[name], torch.float32).data_ptr())
+        self._keep.append(arr)
+        return arr
+
+    def _upload_f32_weights(self) -> None:
+        """fp32 copies of every weight for ``TVC_OPT_TOWER_PRECISION = 1`` (nothing rounded to bf16)."""
+        vw, tw = self._w_host
+        vis = txt = None
+        if vw is not None:
+            vis = _lib.VisionWeights()
+            for name in ("patch_w", "cls", "pos", "ln_pre_g", "ln_pre_b", "ln_post_g", "ln_post_b", "proj"):
+                setattr(vis, name, self._dev(vw[name], torch.float32).data_ptr())
+            vis.layers = C.cast(self._layers_f32(vw["layers"]), C.POINTER(_lib.LayerWeights))
+            self._keep.append(vis)
+        if tw is not None:
+            txt = _lib.TextWeights()
+            for name in ("tok_emb", "pos", "ln_final_g", "ln_final_b", "proj"):
+                setattr(txt, name, self._dev(tw[name], torch.float32).data_ptr())
+            txt.layers = C.cast(self._layers_f32(tw["layers"]), C.POINTER(_lib.LayerWeights))
+            self._keep.append(txt)
+        self._check(self.lib.tvc_set_weights_f32(self.handle, C.byref(vis) if vis is not None else None,
+                                                 C.byref(txt) if txt is not None else None))
+        self._has_f32 = True
+
+    def set_precision(self, precision: str) -> None:
+        """``"bf16"`` (default: bf16 MFMA towers, the benchmarked path) or ``"fp32"`` (fp32-grade towers: exact-f32
+        matrix instructions on the caller's fp32 weights -- embeddings within ~1e-6 of the reference's fp32 CPU path;
+        about 10x slower; validation / attack-generation mode)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32' (got {precision!r})")
+        with self._lock, torch.cuda.device(self.device):
+            if precision == "fp32" and not self._has_f32:
+                if self._w_host[0] is None and self._w_host[1] is None:
+                    raise _lib.TVCError(_lib.TVC_E_STATE, "this engine has no towers to run in fp32")
+                self._upload_f32_weights()
+            self._check(self.lib.tvc_set_option(self.handle, _lib.TVC_OPT_TOWER_PRECISION, int(precision == "fp32")))
+        self.precision = precision
+
     def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
         d = t.detach().to(device=self.device, dtype=dtype).contiguous()
         self._keep.append(d)
@@ -466,6 +513,30 @@ class TVCEngine:
             self._check(self.lib.tvc_layernorm_backward(self.handle, _ptr(x), _ptr(dy), _ptr(g), _ptr(dres), _ptr(dx),
                                                         x.shape[0], x.shape[1], _stream()))
         return dx
+
+    def gemm_f32(self, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out[j, i] (op)= sum_k x[j, k] w[i, k] + bias[i] on the exact-f32 matrix instruction (fp32-grade mode)."""
+        w = _require_cuda(w, torch.float32, "w")
+        x = _require_cuda(x, torch.float32, "x")
+        if w.shape[1] != x.shape[1]:
+            raise ValueError("w [I, K] and x [J, K] expected")
+        if out is None:
+            out = torch.zeros((x.shape[0], w.shape[0]), dtype=torch.float32, device=self.device)
+        if bias is not None:
+            bias = _require_cuda(bias, torch.float32, "bias")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_gemm_f32(self.handle, _ptr(w), _ptr(x), _ptr(bias), _ptr(out), w.shape[0], x.shape[0],
+                                              w.shape[1], out.shape[1], epilogue, _stream()))
+        return out
+
+    def attention_f32(self, qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool) -> torch.Tensor:
+        qkv = _require_cuda(qkv, torch.float32, "qkv")
+        out = torch.empty((qkv.shape[0], heads * 64), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_attention_f32(self.handle, _ptr(qkv), _ptr(out), n_seq, seq_len, heads, int(causal),
+                                                   _stream()))
+        return out
 
     def layernorm(self, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         x = _require_cuda(x, torch.float32, "x")

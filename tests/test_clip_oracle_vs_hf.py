@@ -114,6 +114,45 @@ def test_real_vit_b32_geometry_matches_hf():
     assert torch.equal(pt["tok_emb"].float(), tw["tok_emb"].float())
 
 
+def test_real_vit_l14_geometry_matches_hf():
+    """The geometry every headline number is measured on (BASELINE configs[2..3]: ViT-L/14 -- 24 + 12 layers, widths
+    1024 / 768, heads 16 / 12, patch 14 on 224 x 224, T = 257, projection 768), random weights from a local config:
+    2 images and 4 texts through the oracle's towers and through ``transformers.CLIPModel``."""
+    from transformers import CLIPConfig, CLIPModel
+    cfg = CLIPConfig(
+        vision_config=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                           image_size=224, patch_size=14, hidden_act="quick_gelu"),
+        text_config=dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                         vocab_size=49408, max_position_embeddings=77, hidden_act="quick_gelu",
+                         eos_token_id=49407, bos_token_id=49406, pad_token_id=0),
+        projection_dim=768)
+    torch.manual_seed(2)
+    m = CLIPModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias") or "layer_norm" in n or "layrnorm" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    vw, tw = clip_oracle.from_hf_state_dict(m.state_dict(), 24, 12)
+    x = torch.randn(2, 3, 224, 224)
+    tok = torch.zeros((4, 77), dtype=torch.long)
+    for i, L in enumerate((3, 11, 40, 75)):
+        tok[i, 0] = 49406
+        tok[i, 1:1 + L] = torch.randint(1, 49405, (L,))
+        tok[i, 1 + L] = 49407
+    with torch.no_grad():
+        wi = m.get_image_features(pixel_values=x)
+        wi = getattr(wi, "pooler_output", wi)
+        wt = m.get_text_features(input_ids=tok, attention_mask=(tok != 0).long() | 1)
+        wt = getattr(wt, "pooler_output", wt)
+        gi = clip_oracle.vision_forward(vw, x, heads=16, patch=14, normalize=False)
+        gt = clip_oracle.text_forward(tw, tok, heads=12, normalize=False)
+    assert torch.allclose(gi, wi, atol=5e-5, rtol=2e-4), (gi - wi).abs().max()
+    assert torch.allclose(gt, wt, atol=5e-5, rtol=2e-4), (gt - wt).abs().max()
+    # normalised embeddings (what the scores are functions of): 5e-6 per component
+    ni, nw = gi / gi.norm(dim=-1, keepdim=True), wi / wi.norm(dim=-1, keepdim=True)
+    assert (ni - nw).abs().max().item() < 5e-6
+
+
 def test_text_hidden_states_match_hf_last_hidden_state():
     """oracle.text_hidden == CLIPTextModel.last_hidden_state at every position (what an SD pipeline feeds its UNet)."""
     m = _hf()

@@ -71,8 +71,13 @@ def test_config1_scale_properties(pkg, b32):
     with torch.no_grad():
         ri = clip_oracle.vision_forward(vw, images[-4:].cpu(), arch.vision.heads, arch.patch)
         rt = clip_oracle.text_forward(tw, tokens[-2:].reshape(-1, arch.ctx).cpu().long(), arch.text.heads)
-    assert (fi[-4:].cpu() * ri).sum(-1).min().item() > 0.999
-    assert (ft[-2:].reshape(-1, arch.embed_dim).cpu() * rt).sum(-1).min().item() > 0.999
+    gi, gt = fi[-4:].cpu(), ft[-2:].reshape(-1, arch.embed_dim).cpu()
+    ci, di = (gi * ri).sum(-1).min().item(), (gi - ri).abs().max().item()
+    ct, dt = (gt * rt).sum(-1).min().item(), (gt - rt).abs().max().item()
+    print(f"[measured] ViT-B/32 configs[1] (B = 256 batch) vs oracle (fp32w): image min cos {ci:.6f} max|d| {di:.2e}; "
+          f"text min cos {ct:.6f} max|d| {dt:.2e}")
+    # ~2x the deviation measured at this geometry (configs[0]: image 0.999994 / 5.8e-4, text 0.999969 / 1.3e-3)
+    assert ci > 0.99998 and ct > 0.99993 and di < 1.2e-3 and dt < 2.6e-3
     assert torch.equal(fi, eng.encode_image(images))                       # deterministic
     half = eng.encode_image(images[100:140])
     assert torch.equal(half, fi[100:140])                                   # batch-split invariant

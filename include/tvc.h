@@ -398,6 +398,71 @@ int tvc_attention_backward(tvc_handle* h, const uint16_t* qkv_dev, const uint16_
 int tvc_layernorm_backward(tvc_handle* h, const float* x_dev, const uint16_t* dy_dev, const float* g_dev,
                            const float* dres_dev, float* dx_dev, int32_t rows, int32_t d, void* stream);
 
+/* ---- latent-diffusion reference generator (BASELINE configs[4]) -------------------------
+ * What src/sd_ref.py:389-399 (StableDiffusionModel.generate_image) and experiments/defenses/generative_ref.py:139-147
+ * (sd_model.generate) reach through diffusers.StableDiffusionPipeline: the UNet2DConditionModel denoising loop with
+ * classifier-free guidance under the PNDM (PLMS) scheduler, then AutoencoderKL.decode.  Geometry = the config.json
+ * files the reference holds (cache/sd/models--runwayml--stable-diffusion-v1-5/snapshots/<rev>/{unet,vae,scheduler}).
+ * Activations are bf16 token-major (NHWC) between GEMMs, statistics / softmax / scheduler arithmetic fp32. */
+typedef struct {
+    int32_t in_channels, out_channels;           /* 4, 4                                            */
+    int32_t n_blocks;                            /* 4                                               */
+    int32_t block_out_channels[4];               /* 320, 640, 1280, 1280                            */
+    int32_t down_block_attn[4];                  /* 1, 1, 1, 0 (CrossAttnDownBlock2D x3, DownBlock2D) */
+    int32_t layers_per_block;                    /* 2                                               */
+    int32_t heads;                               /* 8 ("attention_head_dim": 8 = the head count)    */
+    int32_t cross_attention_dim;                 /* 768                                             */
+    int32_t norm_groups;                         /* 32                                              */
+    float   norm_eps;                            /* 1e-5                                            */
+    int32_t vae_n_blocks;                        /* 4                                               */
+    int32_t vae_block_out_channels[4];           /* 128, 256, 512, 512                              */
+    int32_t vae_layers_per_block;                /* 2                                               */
+    int32_t latent_channels;                     /* 4                                               */
+    float   vae_scaling;                         /* 0.18215                                         */
+    int32_t ctx;                                 /* 77                                              */
+    float   beta_start, beta_end;                /* 0.00085, 0.012 (scaled_linear)                  */
+    int32_t num_train_timesteps, steps_offset;   /* 1000, 1                                         */
+} tvc_sd_desc;
+
+typedef struct { const char* name; const void* ptr; } tvc_named_tensor;
+
+/* Register the model.  `tensors` = device pointers keyed by the diffusers state-dict names (UNet names as they are,
+ * VAE names as in AutoencoderKL: "decoder....", "post_quant_conv...."), prepared by the host as follows:
+ *   3x3 conv weight [Co, Ci, 3, 3]  -> bf16 [Co, 9 * Ci], column (ky * 3 + kx) * Ci + ci ("conv_in": zero padded to 64 columns)
+ *   1x1 conv / linear weight        -> bf16 [Co, Ci]
+ *   attn1.to_q|to_k|to_v            -> one bf16 "....attn1.to_qkv.weight" [3C, C];  attn2.to_k|to_v -> "....attn2.to_kv.weight" [2C, 768]
+ *   VAE query|key|value             -> "....to_qkv.weight" bf16 [3C, C] and "....to_qkv.bias" fp32 [3C]
+ *   biases, norm gains / offsets, post_quant_conv.weight [4, 4]  -> fp32
+ * Referenced, not copied (the caller keeps them alive), except the resnets' time projections, which are gathered into
+ * one matrix inside the handle.  Either half may be absent (UNet-only / VAE-only handles). */
+int tvc_sd_load(tvc_handle* h, const tvc_sd_desc* desc, const tvc_named_tensor* tensors, int32_t n_tensors, void* stream);
+
+/* One UNet evaluation: latents fp32 [n, 4, H, W], ctx fp32 [n, ctx, cross_attention_dim] (tvc_encode_text_hidden of
+ * the CLIP ViT-L/14 text tower), scalar timestep -> predicted noise fp32 [n, 4, H, W].  H, W multiples of 8. */
+int tvc_sd_unet(tvc_handle* h, const float* latents_dev, int32_t n, int32_t H, int32_t W, float timestep,
+                const float* ctx_dev, float* eps_dev, void* stream);
+
+/* AutoencoderKL.decode(latents / scaling_factor) -> images fp32 [n, 3, 8H, 8W], (x / 2 + 0.5) clamped to [0, 1]. */
+int tvc_sd_vae_decode(tvc_handle* h, const float* latents_dev, int32_t n, int32_t H, int32_t W, float* images_dev, void* stream);
+
+/* The whole sampling loop for n images: cond / uncond fp32 [n, ctx, cross_attention_dim], latents fp32 [n, 4, H, W]
+ * (in: the initial noise; out: the final latents), `steps` PNDM steps (steps + 1 UNet evaluations on 2n samples each),
+ * guidance scale as in the pipeline; images_dev may be NULL (latents only). */
+int tvc_sd_generate(tvc_handle* h, const float* cond_dev, const float* uncond_dev, float* latents_dev, int32_t n, int32_t H,
+                    int32_t W, int32_t steps, float guidance, float* images_dev, void* stream);
+
+/* One block of the model on fp32 NCHW tensors (parity tests): kind 0 = ResnetBlock2D, 1 = Transformer2DModel, 2 = the
+ * VAE AttentionBlock, 3 = 3x3 conv (stride 1), 4 = stride-2 downsample conv, 5 = nearest-2x upsample + conv;
+ * `prefix` = the block's state-dict prefix with the trailing dot (conv kinds: up to and including "conv." / "conv_in.").
+ * x [n, Cin, H, W]; temb fp32 [n, time_dim] (resnets of the UNet; NULL for the VAE's); ctx as tvc_sd_unet (kind 1);
+ * out [n, Cout, H', W'].  vae != 0 uses the VAE's eps (1e-6). */
+int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x_dev, int32_t n, int32_t Cin, int32_t H,
+                 int32_t W, const float* temb_dev, const float* ctx_dev, int32_t Cout, int32_t vae, float* out_dev, void* stream);
+
+/* Streaming attention of the UNet (parity tests): q [n * Tq, heads * dh], k / v [n * Tk, heads * dh], out like q; bf16. */
+int tvc_sd_attention(tvc_handle* h, const uint16_t* q_dev, const uint16_t* k_dev, const uint16_t* v_dev, uint16_t* out_dev,
+                     int32_t n, int32_t heads, int32_t Tq, int32_t Tk, int32_t dh, void* stream);
+
 /* Building blocks of the fp32-grade tower mode (TVC_OPT_TOWER_PRECISION = 1), exported for parity tests:
  * out[j, i] (op)= sum_k x[j, k] * w[i, k] + bias[i] on the exact-f32 matrix instruction; w fp32 [I, K], x fp32 [J, K],
  * out fp32 [J, ld_out]; K % 4 == 0; epilogue 0 = store, 1 = QuickGELU, 2 = out += (residual add). */

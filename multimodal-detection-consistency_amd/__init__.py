@@ -22,6 +22,8 @@ from .pipeline import (DefensePipeline, MultiModalDetectionPipeline, PipelineCon
 from .ref_bank import ReferenceBank, ReferenceBankConfig, ReferenceItem, create_reference_bank
 from .retrieval import (MultiModalRetriever, RetrievalConfig, RetrievalRefConfig, RetrievalReferenceGenerator,
                         create_retriever, extract_features)
+from .sd_arch import SDArch, make_sd_weights
+from .sd_model import SDKernels, SDModelConfig, StableDiffusionModel, create_sd_model
 from .sd_ref import (GenerationResult, QualityFilter, QualityMetrics, SDReferenceConfig, SDReferenceGenerator,
                      create_sd_reference_generator)
 from .text_variants import TextVariantConfig, TextVariantGenerator

@@ -67,6 +67,22 @@ class ConsistencyParams(C.Structure):
                 ("w_exp", C.c_float * 4)]
 
 
+class SDDesc(C.Structure):
+    """``tvc_sd_desc`` (include/tvc.h)."""
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("n_blocks", C.c_int32),
+                ("block_out_channels", C.c_int32 * 4), ("down_block_attn", C.c_int32 * 4),
+                ("layers_per_block", C.c_int32), ("heads", C.c_int32), ("cross_attention_dim", C.c_int32),
+                ("norm_groups", C.c_int32), ("norm_eps", C.c_float),
+                ("vae_n_blocks", C.c_int32), ("vae_block_out_channels", C.c_int32 * 4),
+                ("vae_layers_per_block", C.c_int32), ("latent_channels", C.c_int32), ("vae_scaling", C.c_float),
+                ("ctx", C.c_int32), ("beta_start", C.c_float), ("beta_end", C.c_float),
+                ("num_train_timesteps", C.c_int32), ("steps_offset", C.c_int32)]
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/tvc.h declares
 SIGNATURES = {
     "tvc_abi_version": (C.c_uint32, []),
@@ -105,6 +121,14 @@ SIGNATURES = {
     "tvc_set_weights_f32": (C.c_int, [_P, C.POINTER(VisionWeights), C.POINTER(TextWeights)]),
     "tvc_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "tvc_attention_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    # latent-diffusion reference generator
+    "tvc_sd_load": (C.c_int, [_P, C.POINTER(SDDesc), C.POINTER(NamedTensor), C.c_int32, _P]),
+    "tvc_sd_unet": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "tvc_sd_vae_decode": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "tvc_sd_generate": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P]),
+    "tvc_sd_block": (C.c_int, [_P, C.c_int32, C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32,
+                               C.c_int32, _P, _P]),
+    "tvc_sd_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 
 _lib = None

@@ -144,3 +144,27 @@ hipError_t launch_attention_f32(const float* qkv, float* out, int n_seq, int T, 
 hipError_t launch_im2col_f32(const float* pix, float* out, int B, int image, int patch, hipStream_t stream);
 hipError_t launch_gather_f32_rows(const float* x, int64_t ld, const int32_t* idx, int64_t idx_mul, float* out, int n,
                                   int d, hipStream_t stream);
+
+// ---- sd_ops.hip / sd_attention.hip: latent-diffusion reference generator (bf16 token-major activations)
+hipError_t sd_im2col3x3(const uint16_t* in, uint16_t* out, int n, int Hi, int Wi, int C, int stride, int up, hipStream_t st);
+hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, int W, int Kp, float scale, hipStream_t st);
+size_t sd_groupnorm_ws_floats(int n, int HW, int groups);
+hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
+                        int n, int HW, int C, int groups, float eps, int silu, float* ws, hipStream_t st);
+hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps, hipStream_t st);
+hipError_t sd_geglu(const uint16_t* in, uint16_t* out, int64_t rows, int Ch, hipStream_t st);
+hipError_t sd_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, hipStream_t st);
+hipError_t sd_concat(const uint16_t* a, int Ca, const uint16_t* b, int Cb, uint16_t* out, int64_t tokens, hipStream_t st);
+hipError_t sd_cast_silu(const float* in, uint16_t* out, int64_t n, int silu, hipStream_t st);
+hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int HW, float mul, float add, int clamp01, hipStream_t st);
+hipError_t sd_pointwise_small(const float* in, const float* w, const float* bias, float* out, int n, int C, int HW, float in_scale, hipStream_t st);
+hipError_t sd_cfg(const float* e, float* out, int64_t n, float g, hipStream_t st);
+hipError_t sd_lincomb(float* out, const float* sample, float cs, float ce, const float* e0, float c0, const float* e1, float c1,
+                      const float* e2, float c2, const float* e3, float c3, int64_t n, hipStream_t st);
+hipError_t sd_softmax_rows(const float* s, uint16_t* p, int64_t rows, int T, float scale, hipStream_t st);
+hipError_t sd_nchw_to_tokens(const float* in, uint16_t* out, int n, int C, int HW, hipStream_t st);
+hipError_t sd_tokens_bf16_to_nchw(const uint16_t* in, float* out, int n, int C, int HW, hipStream_t st);
+hipError_t sd_timestep_embed(uint16_t* out, int n, int dim, float t, hipStream_t st);
+// Q [n * Tq, ldq], K / V [n * Tk, ldk / ldv], O [n * Tq, ldo] bf16; head h = columns [h * dh, (h + 1) * dh); dh % 8 == 0, <= 160
+hipError_t sd_flash_attention(const uint16_t* Q, int64_t ldq, const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv,
+                              uint16_t* O, int64_t ldo, int n, int heads, int Tq, int Tk, int dh, hipStream_t st);

@@ -1,0 +1,472 @@
+// Row / elementwise kernels of the latent-diffusion reference generator (tvc_sd.cpp): everything between the GEMMs of
+// the UNet and the VAE decoder.  Activations are bf16 NHWC -- [n * H * W tokens, C channels], channels contiguous -- so
+// that every convolution is a GEMM over K-contiguous token rows (3x3: rows gathered by im2col3x3_kernel; 1x1: the rows
+// themselves) and every normalisation is a streaming pass; statistics and arithmetic are fp32.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    return u32x4_t{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// ---- 3x3 convolution rows: out[(n, y, x), (ky, kx, c)] = in[n, y*s + ky - 1, x*s + kx - 1, c] (zero outside)
+// `up`: the source is the nearest-2x upsampling of `in` (Upsample2D + conv in one gather).  C % 8 == 0.
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                        int n, int Hi, int Wi, int C, int Ho, int Wo, int stride, int up) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)n * Ho * Wo * 9 * cv;
+    const int Hs = up ? Hi * 2 : Hi, Ws = up ? Wi * 2 : Wi;       // source extent as the convolution sees it
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % cv);
+        int64_t r = t / cv;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const int64_t img = r / Ho;
+        int yy = y * stride + tap / 3 - 1, xx = x * stride + tap % 3 - 1;
+        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) {
+            if (up) { yy >>= 1; xx >>= 1; }
+            v = *(const u32x4_t*)(in + ((img * Hi + yy) * Wi + xx) * C + c * 8);
+        }
+        ((u32x4_t*)out)[t] = v;
+    }
+}
+
+// fp32 NCHW [n, Cin, H, W] (Cin * 9 <= Kp) -> bf16 rows [n * H * W, Kp], column tap * Cin + ci, zero padded;
+// the input is multiplied by `scale` (the VAE's 1 / scaling_factor)
+__global__ __launch_bounds__(256) void im2col_in_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int n,
+                                                        int Cin, int H, int W, int Kp, float scale) {
+    const int64_t total = (int64_t)n * H * W * Kp;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int k = (int)(t % Kp);
+        int64_t r = t / Kp;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int64_t img = r / H;
+        float v = 0.f;
+        if (k < 9 * Cin) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((img * Cin + ci) * H + yy) * W + xx] * scale;
+        }
+        out[t] = f32_to_bf16_bits(v);
+    }
+}
+
+// ---- GroupNorm statistics: thread (token lane, group) walks the tokens of its slab; x' = x + tadd[n, c] (the
+// resnet's time projection, fp32 [n, ld_t]) when given.  part[n][slab][group] = {sum, sumsq} in a fixed order.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
+                                                         int64_t ld_t, float* __restrict__ part, int HW, int C, int groups,
+                                                         int slab_tokens, int nslab) {
+    __shared__ float red[8][32][2];
+    const int img = blockIdx.x / nslab, slab = blockIdx.x - img * nslab;
+    const int g = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int cpg = C / groups;
+    float s = 0.f, q = 0.f;
+    if (g < groups) {
+        const int t1 = min(HW, (slab + 1) * slab_tokens);
+        const float* ta = tadd ? tadd + (int64_t)img * ld_t + g * cpg : nullptr;
+        for (int t = slab * slab_tokens + tl; t < t1; t += 8) {
+            const uint16_t* p = x + ((int64_t)img * HW + t) * C + g * cpg;
+            for (int c = 0; c < cpg; c += 2) {        // cpg is even for every geometry here (checked on the host)
+                const uint32_t w = *(const uint32_t*)(p + c);
+                float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
+                if (ta) { a += ta[c]; b += ta[c + 1]; }
+                s += a + b;
+                q += a * a + b * b;
+            }
+        }
+    }
+    red[tl][g][0] = s; red[tl][g][1] = q;
+    __syncthreads();
+    if (tl == 0 && g < groups) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ss += red[i][g][0]; qq += red[i][g][1]; }
+        float* o = part + (((int64_t)img * nslab + slab) * groups + g) * 2;
+        o[0] = ss; o[1] = qq;
+    }
+}
+
+// stats[n][group] = {mean, rstd}
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nslab,
+                                                         int groups, double count, float eps, int total) {
+    const int i = blockIdx.x * 64 + threadIdx.x;          // (img, group)
+    if (i >= total) return;
+    const int img = i / groups, g = i - img * groups;
+    double s = 0.0, q = 0.0;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const float* p = part + (((int64_t)img * nslab + sl) * groups + g) * 2;
+        s += p[0]; q += p[1];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU; 8 channels per thread
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
+                                                       int64_t ld_t, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       uint16_t* __restrict__ y, int n, int HW, int C, int groups, int silu) {
+    const int cv = C >> 3, cpg = C / groups;
+    const int64_t total = (int64_t)n * HW * cv;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(t % cv) * 8;
+        const int64_t tok = t / cv;
+        const int img = (int)(tok / HW);
+        float f[8];
+        unpack8(((const u32x4_t*)x)[t], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i, g = c / cpg;
+            float v = f[i];
+            if (tadd) v += tadd[(int64_t)img * ld_t + c];
+            v = (v - stats[(img * groups + g) * 2]) * stats[(img * groups + g) * 2 + 1] * gamma[c] + beta[c];
+            f[i] = silu ? silu_f(v) : v;
+        }
+        ((u32x4_t*)y)[t] = pack8(f);
+    }
+}
+
+// ---- LayerNorm over channels, bf16 -> bf16, one wave per row, C % 8 == 0, C <= 1536
+__global__ __launch_bounds__(256) void ln_bf16_kernel(const uint16_t* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, uint16_t* __restrict__ y, int64_t rows,
+                                                      int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cv = C >> 3;
+    const u32x4_t* xr = (const u32x4_t*)(x + row * C);
+    float f[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int v = lane + i * 64;
+        if (v < cv) {
+            unpack8(xr[v], f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int v = lane + i * 64;
+        if (v < cv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    u32x4_t* yr = (u32x4_t*)(y + row * C);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int v = lane + i * 64;
+        if (v < cv) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * g[v * 8 + e] + b[v * 8 + e];
+            yr[v] = pack8(o);
+        }
+    }
+}
+
+// ---- GEGLU: in [rows, 2 * Ch] (value | gate) -> out [rows, Ch] = value * gelu(gate), exact (erf) GELU
+__global__ __launch_bounds__(256) void geglu_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows,
+                                                    int Ch) {
+    const int cv = Ch >> 3;
+    const int64_t total = rows * cv;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % cv);
+        const int64_t r = t / cv;
+        float a[8], g[8];
+        unpack8(*(const u32x4_t*)(in + r * 2 * Ch + c * 8), a);
+        unpack8(*(const u32x4_t*)(in + r * 2 * Ch + Ch + c * 8), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] *= 0.5f * g[i] * (1.0f + erff(g[i] * 0.70710678118654752f));
+        *(u32x4_t*)(out + r * Ch + c * 8) = pack8(a);
+    }
+}
+
+// ---- out = a + b (bf16, n8 pieces of 8)
+__global__ __launch_bounds__(256) void add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                       uint16_t* __restrict__ out, int64_t n8) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n8; t += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        unpack8(((const u32x4_t*)a)[t], x);
+        unpack8(((const u32x4_t*)b)[t], y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] += y[i];
+        ((u32x4_t*)out)[t] = pack8(x);
+    }
+}
+
+// ---- channel concatenation of two token-major tensors: out[t] = a[t] | b[t]
+__global__ __launch_bounds__(256) void concat_kernel(const uint16_t* __restrict__ a, int Ca, const uint16_t* __restrict__ b,
+                                                     int Cb, uint16_t* __restrict__ out, int64_t tokens) {
+    const int cv = (Ca + Cb) >> 3, ca8 = Ca >> 3;
+    const int64_t total = tokens * cv;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % cv);
+        const int64_t r = t / cv;
+        ((u32x4_t*)out)[t] = c < ca8 ? *(const u32x4_t*)(a + r * Ca + c * 8) : *(const u32x4_t*)(b + r * Cb + (c - ca8) * 8);
+    }
+}
+
+// ---- fp32 -> bf16 with optional SiLU (time-embedding MLP)
+__global__ __launch_bounds__(256) void cast_silu_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n,
+                                                        int silu) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const float v = in[t];
+        out[t] = f32_to_bf16_bits(silu ? silu_f(v) : v);
+    }
+}
+
+// ---- fp32 token-major [n * HW, ld] (first C columns) -> fp32 NCHW [n, C, H, W]; out = in * mul + add, optional clamp
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
+                                                             int n, int C, int HW, float mul, float add, int clamp01) {
+    const int64_t total = (int64_t)n * C * HW;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int p = (int)(t % HW);
+        int64_t r = t / HW;
+        const int c = (int)(r % C);
+        const int64_t img = r / C;
+        float v = in[(img * HW + p) * ld + c] * mul + add;
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        out[t] = v;
+    }
+}
+
+// ---- out = bias[c] + sum_ci w[c, ci] * in[n, ci, p] (the VAE's 1x1 post_quant_conv on C <= 8 fp32 channels)
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int n,
+                                                              int C, int HW, float in_scale) {
+    const int64_t total = (int64_t)n * C * HW;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int p = (int)(t % HW);
+        int64_t r = t / HW;
+        const int c = (int)(r % C);
+        const int64_t img = r / C;
+        float v = bias[c];
+        for (int ci = 0; ci < C; ++ci) v += w[c * C + ci] * (in[(img * C + ci) * HW + p] * in_scale);
+        out[t] = v;
+    }
+}
+
+// ---- classifier-free guidance: eps = eu + g * (ec - eu); e = [uncond half | cond half], each n elements
+__global__ __launch_bounds__(256) void cfg_kernel(const float* __restrict__ e, float* __restrict__ out, int64_t n, float g) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const float eu = e[t], ec = e[n + t];
+        out[t] = eu + g * (ec - eu);
+    }
+}
+
+// ---- out = cs * sample - ce * (c0 e0 + c1 e1 + c2 e2 + c3 e3)   (the PLMS update; unused e_i may be NULL with c_i = 0)
+__global__ __launch_bounds__(256) void lincomb_kernel(float* __restrict__ out, const float* __restrict__ sample, float cs, float ce,
+                                                      const float* __restrict__ e0, float c0, const float* __restrict__ e1, float c1,
+                                                      const float* __restrict__ e2, float c2, const float* __restrict__ e3, float c3,
+                                                      int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        float m = c0 * e0[t];
+        if (e1) m += c1 * e1[t];
+        if (e2) m += c2 * e2[t];
+        if (e3) m += c3 * e3[t];
+        out[t] = cs * sample[t] - ce * m;
+    }
+}
+
+// ---- row softmax of fp32 scores (already scaled) -> bf16 probabilities; one workgroup per row, T <= 16384
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, uint16_t* __restrict__ p, int T, float scale) {
+    __shared__ float red[4];
+    const float* sr = s + (int64_t)blockIdx.x * T;
+    uint16_t* pr = p + (int64_t)blockIdx.x * T;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < T; i += 256) mx = fmaxf(mx, sr[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < T; i += 256) sum += __expf(sr[i] * scale - mx);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x; i < T; i += 256) pr[i] = f32_to_bf16_bits(__expf(sr[i] * scale - mx) * inv);
+}
+
+// ---- layout converters of the block-level entry points: fp32 NCHW <-> bf16 token-major
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int n, int C,
+                                                             int HW) {
+    const int64_t total = (int64_t)n * HW * C;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % C);
+        int64_t r = t / C;
+        const int p = (int)(r % HW);
+        const int64_t img = r / HW;
+        out[t] = f32_to_bf16_bits(in[(img * C + c) * HW + p]);
+    }
+}
+__global__ __launch_bounds__(256) void tokens_bf16_to_nchw_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int n,
+                                                                  int C, int HW) {
+    const int64_t total = (int64_t)n * C * HW;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int p = (int)(t % HW);
+        int64_t r = t / HW;
+        const int c = (int)(r % C);
+        const int64_t img = r / C;
+        out[t] = bf16_bits_to_f32(in[(img * HW + p) * C + c]);
+    }
+}
+
+// ---- sinusoidal timestep embedding (flip_sin_to_cos, freq_shift 0): out bf16 [n, dim] = [cos | sin](t * 10000^(-i / half))
+__global__ __launch_bounds__(256) void timestep_embed_kernel(uint16_t* __restrict__ out, int n, int dim, float t) {
+    const int half = dim >> 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n * dim; i += gridDim.x * 256) {
+        const int k = i % dim;
+        const int j = k < half ? k : k - half;
+        const float ang = t * expf(-9.210340371976184f * (float)j / (float)half);
+        out[i] = f32_to_bf16_bits(k < half ? cosf(ang) : sinf(ang));
+    }
+}
+
+inline int grid_for(int64_t total) {
+    const int64_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+}  // namespace
+
+hipError_t sd_im2col3x3(const uint16_t* in, uint16_t* out, int n, int Hi, int Wi, int C, int stride, int up, hipStream_t st) {
+    if (C % 8 != 0 || (stride != 1 && stride != 2) || (up && stride != 1)) return hipErrorInvalidValue;
+    const int Hs = up ? 2 * Hi : Hi, Ws = up ? 2 * Wi : Wi;
+    const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;       // padding 1, kernel 3
+    const int64_t total = (int64_t)n * Ho * Wo * 9 * (C >> 3);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, n, Hi, Wi, C, Ho, Wo, stride, up);
+    return hipGetLastError();
+}
+
+hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, int W, int Kp, float scale, hipStream_t st) {
+    if (9 * Cin > Kp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(im2col_in_kernel, dim3(grid_for((int64_t)n * H * W * Kp)), dim3(256), 0, st, in, out, n, Cin, H, W, Kp, scale);
+    return hipGetLastError();
+}
+
+// ws: >= n * nslab * groups * 2 + n * groups * 2 floats (sd_groupnorm_ws_floats)
+size_t sd_groupnorm_ws_floats(int n, int HW, int groups) {
+    const int slab = 256;
+    const int nslab = (HW + slab - 1) / slab;
+    return (size_t)n * nslab * groups * 2 + (size_t)n * groups * 2;
+}
+
+hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
+                        int n, int HW, int C, int groups, float eps, int silu, float* ws, hipStream_t st) {
+    if (groups > 32 || C % groups != 0 || (C / groups) % 2 != 0 || C % 8 != 0) return hipErrorInvalidValue;
+    const int slab = 256;
+    const int nslab = (HW + slab - 1) / slab;
+    float* part = ws;
+    float* stats = ws + (size_t)n * nslab * groups * 2;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), 0, st, x, tadd, ld_t, part, HW, C, groups, slab, nslab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 63) / 64), dim3(64), 0, st, part, stats, nslab, groups,
+                       (double)HW * (C / groups), eps, n * groups);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((int64_t)n * HW * (C >> 3))), dim3(256), 0, st, x, tadd, ld_t, stats, gamma,
+                       beta, y, n, HW, C, groups, silu);
+    return hipGetLastError();
+}
+
+hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps,
+                             hipStream_t st) {
+    if (C % 8 != 0 || C > 1536) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, y, rows, C, eps);
+    return hipGetLastError();
+}
+
+hipError_t sd_geglu(const uint16_t* in, uint16_t* out, int64_t rows, int Ch, hipStream_t st) {
+    if (Ch % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for(rows * (Ch >> 3))), dim3(256), 0, st, in, out, rows, Ch);
+    return hipGetLastError();
+}
+
+hipError_t sd_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, hipStream_t st) {
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, st, a, b, out, n >> 3);
+    return hipGetLastError();
+}
+
+hipError_t sd_concat(const uint16_t* a, int Ca, const uint16_t* b, int Cb, uint16_t* out, int64_t tokens, hipStream_t st) {
+    if (Ca % 8 != 0 || Cb % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(concat_kernel, dim3(grid_for(tokens * ((Ca + Cb) >> 3))), dim3(256), 0, st, a, Ca, b, Cb, out, tokens);
+    return hipGetLastError();
+}
+
+hipError_t sd_cast_silu(const float* in, uint16_t* out, int64_t n, int silu, hipStream_t st) {
+    hipLaunchKernelGGL(cast_silu_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, n, silu);
+    return hipGetLastError();
+}
+
+hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int HW, float mul, float add, int clamp01,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(grid_for((int64_t)n * C * HW)), dim3(256), 0, st, in, ld, out, n, C, HW, mul, add,
+                       clamp01);
+    return hipGetLastError();
+}
+
+hipError_t sd_pointwise_small(const float* in, const float* w, const float* bias, float* out, int n, int C, int HW, float in_scale,
+                              hipStream_t st) {
+    if (C > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pointwise_small_kernel, dim3(grid_for((int64_t)n * C * HW)), dim3(256), 0, st, in, w, bias, out, n, C, HW,
+                       in_scale);
+    return hipGetLastError();
+}
+
+hipError_t sd_cfg(const float* e, float* out, int64_t n, float g, hipStream_t st) {
+    hipLaunchKernelGGL(cfg_kernel, dim3(grid_for(n)), dim3(256), 0, st, e, out, n, g);
+    return hipGetLastError();
+}
+
+hipError_t sd_lincomb(float* out, const float* sample, float cs, float ce, const float* e0, float c0, const float* e1, float c1,
+                      const float* e2, float c2, const float* e3, float c3, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, sample, cs, ce, e0, c0, e1, c1, e2, c2, e3, c3, n);
+    return hipGetLastError();
+}
+
+hipError_t sd_softmax_rows(const float* s, uint16_t* p, int64_t rows, int T, float scale, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, p, T, scale);
+    return hipGetLastError();
+}
+
+hipError_t sd_nchw_to_tokens(const float* in, uint16_t* out, int n, int C, int HW, hipStream_t st) {
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(grid_for((int64_t)n * C * HW)), dim3(256), 0, st, in, out, n, C, HW);
+    return hipGetLastError();
+}
+
+hipError_t sd_tokens_bf16_to_nchw(const uint16_t* in, float* out, int n, int C, int HW, hipStream_t st) {
+    hipLaunchKernelGGL(tokens_bf16_to_nchw_kernel, dim3(grid_for((int64_t)n * C * HW)), dim3(256), 0, st, in, out, n, C, HW);
+    return hipGetLastError();
+}
+
+hipError_t sd_timestep_embed(uint16_t* out, int n, int dim, float t, hipStream_t st) {
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(grid_for((int64_t)n * dim)), dim3(256), 0, st, out, n, dim, t);
+    return hipGetLastError();
+}

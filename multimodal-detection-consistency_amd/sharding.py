@@ -19,10 +19,17 @@ Two independent axes:
         m = 5120, kf = 5, D = 768) -- xGMI is point-to-point, every link carries a
         distinct peer's slice;
      d. ``tvc_topk_merge`` merges the W sorted partials (HIP kernel).
-   With ``rows_per_shard`` given, (c) carries indices + similarities only and two small
-   variable-size all-to-alls (e, f) fetch just the winners' rows from their owners: every DISTINCT
-   winner once (the N+1 text rows of a query mostly retrieve the same references), in bf16 when the
-   bank is bf16 (exact), and none for the image rows of a detection batch (``feat_from``).
+   **Default form ("fused", no host synchronisation at all):** (c) is ONE ``all_to_all_single`` of fixed-size
+   slots -- per peer: the m x k index / similarity lists and the rows of the kf best of every row that needs
+   references (none for the image rows of a detection batch, ``feat_from``), in bf16 when the bank is bf16
+   (exact): 35 MB per link and step at m = 5120, kf = 5, D = 768, against 7 links x ~50 GB/s.  The local
+   search is the asynchronous one; ``check_status`` (one read-back per STEP, next to the records' own copy)
+   reports a candidate-list overflow on any rank to every rank.  Every tensor size is known on the host in
+   advance, so a step enqueues its collectives behind the kernels and returns: the exchange of batch i runs
+   under the towers of batch i + 1 (``bench.py --shard-bank`` pipelines exactly that).
+   With ``rows_per_shard`` given AND ``mode="two_phase"``, (c) carries indices + similarities only and two
+   variable-size all-to-alls (e, f) fetch just the DISTINCT winners' rows from their owners (fewest bytes,
+   but three host read-backs per step: for links far slower than xGMI).
    The ``[M, R]`` similarity rows are never exchanged.
 
 The collectives move small tensors; all arithmetic stays in the HIP kernels.
@@ -70,6 +77,22 @@ class HipShardOps:
         idx, sim, _ = self.engine.bank_search_robust(rows, k, self.count_thr, idx_offset=self.row_offset,
                                                      want_moments=False)
         return idx, sim
+
+    def search_async(self, rows: torch.Tensor, k: int):
+        """The same search enqueued without a status read-back (``check`` reports an overflow later)."""
+        idx, sim, _ = self.engine.bank_search(rows, k, self.count_thr, idx_offset=self.row_offset, want_moments=False)
+        return idx, sim
+
+    def check(self) -> bool:
+        """Synchronises; True if the last ``search_async`` overflowed its candidate lists on this shard."""
+        from . import _lib
+        try:
+            self.engine.bank_status()
+            return False
+        except _lib.TVCError as e:
+            if e.code != _lib.TVC_E_OVERFLOW:
+                raise
+            return True
 
     def gather(self, idx: torch.Tensor):
         return self.engine.bank_gather(idx.contiguous(), idx_offset=self.row_offset)
@@ -128,18 +151,84 @@ class ShardedBankSearch:
     shard that owns it): ``m x kf x D x 4 B`` per rank instead of W times that.  Without it the
     single-phase form (every shard ships the rows of its own kf best) is used."""
 
-    def __init__(self, ops: ShardOps, group=None, rows_per_shard: Optional[int] = None):
+    def __init__(self, ops: ShardOps, group=None, rows_per_shard: Optional[int] = None, mode: Optional[str] = None):
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.rows_per_shard = rows_per_shard
+        # "fused": one fixed-size all-to-all, no host synchronisation (default); "two_phase": fewest bytes (needs
+        # rows_per_shard); "single_phase": the round-1 form (fp32 rows of every shard's kf best)
+        self.mode = mode or "fused"
+        if self.mode not in ("fused", "two_phase", "single_phase"):
+            raise ValueError(f"unknown exchange mode {self.mode!r}")
+        if self.mode == "two_phase" and rows_per_shard is None:
+            raise ValueError("the two-phase exchange needs rows_per_shard")
+        self.last_exchange = {}
+
+    # ---- the sync-free form ------------------------------------------------------------------------------
+    def search_fused(self, rows: torch.Tensor, k: int, kf: int, feat_from: int = 0):
+        """(a) all-gather of the query rows, (b) asynchronous local search + gather of the kf best rows of every row
+        that needs references, (c) ONE all-to-all of fixed-size slots [idx | sim | rows], (d) merge.  Nothing here
+        reads a value back to the host: call ``check_status`` once per step."""
+        W, (m, D), dev = self.world, rows.shape, rows.device
+        need = m - feat_from
+        allrows = torch.empty((W * m, D), dtype=rows.dtype, device=dev)
+        dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)          # (a)
+        search = getattr(self.ops, "search_async", self.ops.search)
+        idx, sim = search(allrows, k)                                                       # (b) [W*m, k], global indices
+        tdt = getattr(self.ops, "transport_dtype", torch.float32)
+        esz = 2 if tdt == torch.bfloat16 else 4
+        n_is = m * k * 4
+        n_ft = (need * kf * D * esz + 15) // 16 * 16
+        slot = 2 * ((n_is + 15) // 16 * 16) + n_ft
+        o_sim, o_ft = (n_is + 15) // 16 * 16, 2 * ((n_is + 15) // 16 * 16)
+        send = torch.empty((W, slot), dtype=torch.uint8, device=dev)
+        send[:, :n_is].view(torch.int32).copy_(idx.view(W, m * k))
+        send[:, o_sim:o_sim + n_is].view(torch.float32).copy_(sim.view(W, m * k))
+        if need > 0:
+            widx = idx.view(W, m, k)[:, feat_from:, :kf].reshape(W * need, kf)
+            feat = self.ops.gather(widx.contiguous())                                       # [W*need, kf, D] fp32
+            send[:, o_ft:o_ft + need * kf * D * esz].view(tdt).copy_(feat.view(W, need * kf * D))
+        recv = torch.empty_like(send)
+        _all_to_all(recv, send, self.group)                                                 # (c)
+        idx_in = recv[:, :n_is].view(torch.int32).reshape(W, m, k)
+        sim_in = recv[:, o_sim:o_sim + n_is].view(torch.float32).reshape(W, m, k)
+        out_feat = torch.zeros((m, kf, D), dtype=torch.float32, device=dev)
+        if feat_from > 0 or need == 0:
+            hi, hs, _ = self.ops.merge(idx_in[:, :m - need].contiguous(), sim_in[:, :m - need].contiguous(), None)
+        if need > 0:
+            feat_in = recv[:, o_ft:o_ft + need * kf * D * esz].view(tdt).reshape(W, need, kf, D).to(torch.float32)
+            ti, ts, tf = self.ops.merge(idx_in[:, feat_from:].contiguous(), sim_in[:, feat_from:].contiguous(), feat_in)   # (d)
+            out_feat[feat_from:] = tf
+            midx, msim = (torch.cat([hi, ti]), torch.cat([hs, ts])) if feat_from > 0 else (ti, ts)
+        else:
+            midx, msim = hi, hs
+        self.last_exchange = {"mode": "fused", "bytes_per_peer": int(slot), "host_syncs": 0,
+                              "rows_sent": int(W * need * kf), "bytes_per_row": D * esz}
+        return midx, msim, out_feat
+
+    def check_status(self) -> None:
+        """One read-back per step: raise ``TVCError(TVC_E_OVERFLOW)`` on EVERY rank if the asynchronous search of any
+        rank dropped candidates (degenerate shard); the caller then repeats the step with ``mode="two_phase"`` /
+        the status-checked search, whose brute-force fallback is local to the shard."""
+        from . import _lib
+        over = bool(getattr(self.ops, "check", lambda: False)())
+        if self.world > 1:
+            t = torch.tensor([1.0 if over else 0.0])
+            t = t.cuda() if dist.get_backend(self.group) == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            over = bool(t.item() > 0)
+        if over:
+            raise _lib.TVCError(_lib.TVC_E_OVERFLOW, "sharded bank search: a shard's candidate lists overflowed")
 
     def search(self, rows: torch.Tensor, k: int, kf: int, feat_from: int = 0):
         """rows [m, D] (this rank's query-side rows; m equal on every rank) ->
         idx [m, k] global, sim [m, k], feat [m, kf, D] of the kf best.  ``feat_from``: the first ``feat_from``
         rows need no feature rows (the image rows of a detection batch: only the text rows' references are
-        compared with the image) -- their feat stays zero and nothing travels for them (two-phase form)."""
+        compared with the image) -- their feat stays zero and nothing travels for them."""
+        if self.mode == "fused":
+            return self.search_fused(rows, k, kf, feat_from)
         W, (m, D) = self.world, rows.shape
         allrows = torch.empty((W * m, D), dtype=rows.dtype, device=rows.device)
         dist.all_gather_into_tensor(allrows, rows.contiguous(), group=self.group)         # (a)
@@ -148,7 +237,7 @@ class ShardedBankSearch:
         sim_in = torch.empty((W, m, k), dtype=sim.dtype, device=rows.device)
         _all_to_all(idx_in, idx.view(W, m, k), self.group)                                 # (c)
         _all_to_all(sim_in, sim.view(W, m, k), self.group)
-        if self.rows_per_shard is None:
+        if self.mode == "single_phase":
             feat = self.ops.gather(idx[:, :kf])
             feat_in = torch.empty((W, m, kf, D), dtype=feat.dtype, device=rows.device)
             _all_to_all(feat_in, feat.view(W, m, kf, D), self.group)
@@ -171,7 +260,8 @@ class ShardedBankSearch:
                 ufeat[pos[w]] = got[w].to(torch.float32)
         feat = torch.zeros((m, kf, D), dtype=torch.float32, device=rows.device)
         feat[feat_from:] = ufeat[inv].view(m - feat_from, kf, D)
-        self.last_exchange = {"rows_sent": int(sum(t.shape[0] for t in sent)), "distinct_winners": int((uniq >= 0).sum()),
+        self.last_exchange = {"mode": "two_phase", "host_syncs": 3,
+                              "rows_sent": int(sum(t.shape[0] for t in sent)), "distinct_winners": int((uniq >= 0).sum()),
                               "winner_slots": int(win.numel()), "bytes_per_row": D * (2 if tdt == torch.bfloat16 else 4)}
         return midx, msim, feat
 

@@ -64,7 +64,8 @@ class NumpyShardOps:
         return torch.from_numpy(oi), torch.from_numpy(osim), torch.from_numpy(of)
 
 
-def _worker(rank, world, port, R, D, m, k, kf, out_dir, two_phase):
+def _worker(rank, world, port, R, D, m, k, kf, out_dir, mode):
+    two_phase = mode == "two_phase"
     sys.path.insert(0, str(ROOT))
     import importlib
     pkg = importlib.import_module("multimodal-detection-consistency_amd")
@@ -78,7 +79,7 @@ def _worker(rank, world, port, R, D, m, k, kf, out_dir, two_phase):
     q_all /= np.linalg.norm(q_all, axis=1, keepdims=True)
     lo, hi = pkg.sharding.shard_bounds(R, world, rank)
     per = (R + world - 1) // world
-    search = pkg.sharding.ShardedBankSearch(NumpyShardOps(bank[lo:hi], lo), rows_per_shard=per if two_phase else None)
+    search = pkg.sharding.ShardedBankSearch(NumpyShardOps(bank[lo:hi], lo), rows_per_shard=per if two_phase else None, mode=mode)
     mine = torch.from_numpy(q_all[rank * m:(rank + 1) * m]).clone()
     mine[m - 1] = mine[m - 2]                      # two query rows with the same winners: each distinct row travels once
     idx, sim, feat = search.search(mine, k, kf)
@@ -91,17 +92,25 @@ def _worker(rank, world, port, R, D, m, k, kf, out_dir, two_phase):
         assert torch.equal(i2, idx) and torch.equal(s2, sim)
         assert torch.equal(f2[2:], feat[2:]) and float(f2[:2].abs().max()) == 0.0
         assert search.last_exchange["winner_slots"] == (m - 2) * kf
+    if mode == "fused":
+        assert search.last_exchange["host_syncs"] == 0
+        search.check_status()                         # the numpy stand-in never overflows: must pass on both ranks
+        i2, s2, f2 = search.search(mine, k, kf, feat_from=2)
+        assert torch.equal(i2, idx) and torch.equal(s2, sim)
+        assert torch.equal(f2[2:], feat[2:]) and float(f2[:2].abs().max()) == 0.0
+        i3, s3, f3 = search.search(mine, k, kf, feat_from=m)      # no row needs references
+        assert torch.equal(i3, idx) and float(f3.abs().max()) == 0.0
     np.savez(Path(out_dir) / f"r{rank}.npz", idx=idx.numpy(), sim=sim.numpy(), feat=feat.numpy(), bank=bank, q=mine.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("two_phase", [False, True])
+@pytest.mark.parametrize("mode", ["fused", "single_phase", "two_phase"])
 @pytest.mark.parametrize("R", [1001, 7])
-def test_sharded_search_matches_global(tmp_path, R, two_phase):
+def test_sharded_search_matches_global(tmp_path, R, mode):
     world, D, m, k, kf = 2, 32, 6, 5, 3
-    port = 29500 + (os.getpid() % 2000) + R % 7 + 11 * int(two_phase)
-    mp.spawn(_worker, args=(world, port, R, D, m, k, kf, str(tmp_path), two_phase), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + R % 7 + 11 * ["fused", "single_phase", "two_phase"].index(mode)
+    mp.spawn(_worker, args=(world, port, R, D, m, k, kf, str(tmp_path), mode), nprocs=world, join=True)
     for rank in range(world):
         g = np.load(tmp_path / f"r{rank}.npz")
         S = g["q"].astype(np.float64) @ g["bank"].astype(np.float64).T

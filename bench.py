@@ -55,6 +55,9 @@ def parse(argv=None):
     p.add_argument("--shard-bank", action="store_true",
                    help="BASELINE configs[3]: --bank-rows is the GLOBAL bank, row-sharded over the ranks; "
                         "partial top-k lists are exchanged with RCCL (all-gather + all-to-all) and merged on the GPU")
+    p.add_argument("--exchange", default="fused", choices=["fused", "two_phase", "single_phase"],
+                   help="--shard-bank: how the partial lists travel (sharding.py); fused = one fixed-size all-to-all, "
+                        "no host synchronisation, pipelined under the next batch's towers (default)")
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the process group is "
                         "gloo (RCCL refuses two ranks on one device); checks the launch contract, not speed")
@@ -255,8 +258,9 @@ def main():
         bank = pkg.synth.plant_neighbours(bank, ft0.cpu(), per_anchor=1, seed=11 + rank)
         del ft0
     if a.shard_bank:
+        # "fused": ONE fixed-size all-to-all per step, no host read-back inside the search (sharding.py)
         sharded = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(eng, lo, 0.3),
-                                                 rows_per_shard=(R + world - 1) // world)
+                                                 rows_per_shard=(R + world - 1) // world, mode=a.exchange)
     eng.set_bank(bank)
     if a.dense_text:
         eng.set_option(pkg._lib.TVC_OPT_TEXT_PACKING, 0)
@@ -267,7 +271,37 @@ def main():
 
     s_img, s_txt = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
+    def towers():
+        """Both towers of one batch on their own streams; returns (fi, ft, event that marks both done)."""
+        main = torch.cuda.current_stream()
+        s_txt.wait_stream(main); s_img.wait_stream(main)
+        with torch.cuda.stream(s_txt):
+            ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx), group=0 if a.no_prefix_sharing else N + 1)
+        with torch.cuda.stream(s_img):
+            fi = eng.encode_image(images)
+        return fi, ft
+
+    pipe_state = {}
+
+    def step_sharded_pipelined():
+        """--shard-bank, fused exchange: nothing between the towers and the records reads a value back, so the host
+        enqueues batch i + 1's towers (their own streams) BEFORE batch i's search / exchange / consistency (main stream):
+        the all-gather and the all-to-all of batch i run under the towers of batch i + 1.  One step =
+        one batch retired; the pipeline is primed in the warm-up and drained by the closing synchronize."""
+        main = torch.cuda.current_stream()
+        if "next" not in pipe_state:
+            pipe_state["next"] = towers()
+        fi, ft = pipe_state["next"]
+        main.wait_stream(s_txt); main.wait_stream(s_img)          # batch i's embeddings are ready for the main stream
+        pipe_state["next"] = towers()                             # batch i + 1: enqueued now, runs beside what follows
+        rows = torch.cat([fi, ft])
+        idx, sim, feat = sharded.search(rows, k, cfg.reference_count, feat_from=B)
+        rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, idx[B:].contiguous(), sim[B:].contiguous(), feat[B:].contiguous())
+        return rec.cpu(), idx[:B].cpu()
+
     def step(serial=False):
+        if a.shard_bank and a.exchange == "fused" and not serial and not a.serial_towers:
+            return step_sharded_pipelined()
         if a.serial_towers or serial:
             ft = eng.encode_text(tokens.view(B * (N + 1), arch.ctx), group=0 if a.no_prefix_sharing else N + 1)   # first: its one row-count read-back
             fi = eng.encode_image(images)                               # happens while the GPU is still idle
@@ -305,6 +339,8 @@ def main():
             out = fn()
         if not a.shard_bank:
             eng.bank_status()
+        elif a.exchange == "fused":
+            sharded.check_status()            # the asynchronous search: one status read-back, outside the timed region
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -318,7 +354,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if not a.shard_bank:
-        eng.bank_status()                     # (the sharded search is status-checked per call)
+        eng.bank_status()
+    elif a.exchange == "fused":
+        sharded.check_status()                # (the other exchange modes are status-checked per call)
     assert torch.isfinite(rec[:, :11]).all()      # words >= 12+N hold int32 bit patterns (-1 = NaN bits)
     kept_refs = float(rec[:, 8].mean())           # references kept per query by the consistency kernel
 
@@ -395,6 +433,8 @@ def main():
                 out["bank_stage"] = {"mfma_tflops": round(bk["work"] / (bk["ms"] * 1e-3) / 1e12, 1),
                                      "bank_stream_GBps": round(bank.shape[0] * D * 2 / (bk["ms"] * 1e-3) / 1e9, 1)}
 
+    if rank == 0 and a.shard_bank:
+        out["exchange"] = dict(sharded.last_exchange)
     extras = world == 1 and not a.no_extras and not a.shard_bank
     if extras and not a.dense_text:
         # the same workload with the text tower on all 77 positions (no EOT packing): the rate does not
@@ -484,6 +524,86 @@ def main():
                                  "gemm_tflops_in_step": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1),
                                  "gemm_gflop_per_image_step": round(fwd_flop / 1e9, 1),
                                  "note": "forward (the backward's inputs are kept, nothing is recomputed) + the four dX GEMMs per layer; no weight gradients"}
+
+    if extras and B >= 256 and a.model == "ViT-L/14":
+        # ---- the same inner loop at a full chip: batch 256 (the reference's 32 is a default of PGDAttackConfig, not a
+        # constraint of PGDAttacker.perturb; the kept activations are 31 GB of the 288 GB)
+        pb = 256
+        clean = images[:pb].contiguous()
+        adv, mom = clean.clone(), torch.zeros_like(clean)
+        g_out = (eng.encode_text(tokens[:pb, 0].contiguous()) / pb).contiguous()
+
+        def pgd_iter256():
+            eng.encode_image_grad(adv, True)
+            g = eng.encode_image_backward(g_out)
+            eng.pgd_step(adv, clean, g, mom, 8 / 255, 2 / 255, 0.9, 0.0, 1.0, False)
+
+        eng.profile_begin()
+        pgd_iter256(); sync()
+        prof = eng.profile_end()
+        d_pgd, _ = timed(pgd_iter256, 5, 1)
+        out["pgd_inner_loop_b256"] = {"image_steps_per_s": round(pb * 5 / d_pgd, 1), "batch": pb, "ms_per_step": round(d_pgd / 5 * 1e3, 2),
+                                      "gemm_tflops_in_step": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1)}
+        del adv, mom, clean
+
+    if extras and a.model == "ViT-L/14":
+        # ---- bank construction (scripts/build_faiss_indices.py:59-120 benchmarks its own QPS): the image
+        # tower streaming synthetic images at B = 512 -> L2-normalised rows -> features.npy in the reference's layout
+        import tempfile
+        import numpy as np
+        n_img = 100 * B if B >= 256 else 20 * B
+        with tempfile.TemporaryDirectory() as td:
+            feats = np.lib.format.open_memmap(os.path.join(td, "features.npy"), mode="w+", dtype=np.float32, shape=(n_img, D))
+            pin = torch.empty((B, D), dtype=torch.float32).pin_memory()
+            sync()
+            t0 = time.perf_counter(); t_write = 0.0
+            prev = None
+            for b0 in range(0, n_img, B):
+                f = eng.encode_image(images)                      # (the same synthetic batch: content does not change the cost)
+                if prev is not None:
+                    tw = time.perf_counter()
+                    feats[prev[0]:prev[0] + B] = prev[1].cpu().numpy()       # batch i - 1 lands while batch i computes
+                    t_write += time.perf_counter() - tw
+                prev = (b0, f)
+            tw = time.perf_counter()
+            feats[prev[0]:prev[0] + B] = prev[1].cpu().numpy()
+            feats.flush()
+            t_write += time.perf_counter() - tw
+            d_build = time.perf_counter() - t0
+        out["bank_build"] = {"images_per_s": round(n_img / d_build, 1), "images": n_img, "batch": B, "seconds": round(d_build, 2),
+                             "writer_share": round(t_write / d_build, 3),
+                             "note": "ViT-L/14 image tower at B=512 -> L2-normalised fp32 rows -> features.npy (np.lib.format memmap); "
+                                     "writer_share = host time inside the D2H copy + file write (mostly waiting for the GPU)"}
+
+    if extras and a.model == "ViT-L/14" and not os.environ.get("TVC_BENCH_NO_SD"):
+        # ---- SD reference generation (BASELINE configs[4]): prompts x seeds denoised together, 20 PNDM
+        # steps (experiments/defenses/generative_ref.py:24) at 64 x 64 latents, guidance 7.5, VAE decode to 512 x 512,
+        # device-side preprocessing, ONE image-tower launch -> reference embeddings
+        torch.cuda.empty_cache()
+        sd = pkg.StableDiffusionModel(pkg.SDModelConfig(device=str(dev)), clip_model=clip)
+        n_img, steps_sd = 12, 20
+        prompts = [f"a photo of object number {i}" for i in range(n_img)]
+        seeds_sd = list(range(n_img))
+
+        def sd_step():
+            imgs = sd.generate_batch(prompts, seeds_sd, steps_sd, 7.5, 512, 512)
+            return eng.encode_image(clip.preprocess_tensor(imgs), True)
+
+        sd_step(); sync()
+        eng.profile_begin()
+        sd_step(); sync()
+        prof = eng.profile_end()
+        d_sd, _ = timed(sd_step, 2, 0)
+        gemm_tf = prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12 if prof["gemm"]["ms"] > 0 else 0.0
+        out["sd_reference"] = {"images_per_s": round(n_img * 2 / d_sd, 3), "images": n_img, "steps": steps_sd, "latent": "64x64",
+                               "seconds_per_batch": round(d_sd / 2, 3),
+                               "unet_evaluations_per_batch": steps_sd + 1, "samples_per_evaluation": 2 * n_img,
+                               "kernel_ms_per_batch": {c: round(v["ms"], 1) for c, v in prof.items()},
+                               "gemm_tflops": round(gemm_tf, 1), "gemm_frac_of_peak": round(gemm_tf / PEAK_BF16_DENSE_TFLOPS, 4),
+                               "gemm_tflop_per_image": round(prof["gemm"]["work"] / n_img / 1e12, 2),
+                               "note": "random-init SD-1.5 geometry (no checkpoint without a network); UNet + VAE GEMMs through the tower "
+                                       "GEMM kernel with explicit im2col rows; attention = sd_flash_attention_kernel"}
+        del sd
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         nq = min(B, 64)

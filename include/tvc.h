@@ -313,6 +313,12 @@ int tvc_pgd_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const fl
                  int32_t B, int64_t n, float eps, float alpha, float mu, float clip_min, float clip_max,
                  int32_t targeted, void* stream);
 
+/* The L2-constrained step of the Hubness attack (src/attacks/hubness_attack.py:378-386), in place on adv_dev, per image:
+ *   adv += (descent ? -1 : +1) * step * grad / (|grad|_2 + 1e-8);  d = adv - clean;  d *= min(|d|_2, eps) / (|d|_2 + 1e-8);
+ *   adv = clamp(clean + d, clip_min, clip_max) */
+int tvc_l2_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const float* grad_dev, int32_t B, int64_t n, float eps,
+                float step, float clip_min, float clip_max, int32_t descent, void* stream);
+
 /* ---- per-query consistency (K4, K6, K7) ------------------------------ */
 
 typedef struct {
@@ -462,6 +468,14 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
 /* Streaming attention of the UNet (parity tests): q [n * Tq, heads * dh], k / v [n * Tk, heads * dh], out like q; bf16. */
 int tvc_sd_attention(tvc_handle* h, const uint16_t* q_dev, const uint16_t* k_dev, const uint16_t* v_dev, uint16_t* out_dev,
                      int32_t n, int32_t heads, int32_t Tq, int32_t Tk, int32_t dh, void* stream);
+
+/* Image preprocessing on the device: images fp32 [n, 3, H, W] with values in [0, 1] -> out fp32 [n, 3, S, S]:
+ * antialiased resize of the short side to S (filter 0 = bilinear: torchvision Resize as in
+ * experiments/defenses/generative_ref.py:55-59 -- which resizes BOTH sides to S; 1 = bicubic: the CLIP preprocess of
+ * src/attacks/hubness_attack.py:223), centre crop, (x - mean[c]) / std[c].  keep_aspect 0 resizes both sides to S.
+ * PIL / torch(antialias) filter semantics on float pixels (no uint8 rounding). */
+int tvc_preprocess_images(tvc_handle* h, const float* images_dev, int32_t n, int32_t H, int32_t W, int32_t S, int32_t filter,
+                          int32_t keep_aspect, const float* mean3, const float* std3, float* out_dev, void* stream);
 
 /* Building blocks of the fp32-grade tower mode (TVC_OPT_TOWER_PRECISION = 1), exported for parity tests:
  * out[j, i] (op)= sum_k x[j, k] * w[i, k] + bias[i] on the exact-f32 matrix instruction; w fp32 [I, K], x fp32 [J, K],

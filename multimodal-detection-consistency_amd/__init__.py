@@ -24,7 +24,7 @@ from .retrieval import (MultiModalRetriever, RetrievalConfig, RetrievalRefConfig
                         create_retriever, extract_features)
 from .sd_arch import SDArch, make_sd_weights
 from .sd_model import SDKernels, SDModelConfig, StableDiffusionModel, create_sd_model
-from .sd_ref import (GenerationResult, QualityFilter, QualityMetrics, SDReferenceConfig, SDReferenceGenerator,
+from .sd_ref import (GenerativeConfig, GenerativeReferenceGenerator, GenerationResult, QualityFilter, QualityMetrics, SDReferenceConfig, SDReferenceGenerator,
                      create_sd_reference_generator)
 from .text_variants import TextVariantConfig, TextVariantGenerator
 from .variants import TemplateVariantGenerator

@@ -115,6 +115,7 @@ SIGNATURES = {
     "tvc_encode_image_backward": (C.c_int, [_P, _P, _P, _P]),
     "tvc_pgd_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, _P]),
+    "tvc_l2_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, _P]),
     "tvc_attention_backward": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "tvc_layernorm_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     # fp32-grade towers: the *_f32 weight structs have the field order of LayerWeights / VisionWeights / TextWeights
@@ -128,6 +129,8 @@ SIGNATURES = {
     "tvc_sd_generate": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P]),
     "tvc_sd_block": (C.c_int, [_P, C.c_int32, C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32,
                                C.c_int32, _P, _P]),
+    "tvc_preprocess_images": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "tvc_sd_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 

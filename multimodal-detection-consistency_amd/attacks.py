@@ -292,13 +292,13 @@ COMMON_QUERIES = ("a photo of a cat", "a dog playing", "a beautiful landscape", 
 
 class HubnessAttack:
     """Mirror of ``HubnessAttack`` (:131-787).  ``clip_model`` may be injected (the reference builds its own from
-    ``config.clip_model``, :435-462; done here too when none is given).  Only the L-inf constraint is built (the
-    reference's default and the paper's); ``norm_constraint='l2'`` raises."""
+    ``config.clip_model``, :435-462; done here too when none is given).  ``norm_constraint`` 'linf' (default) or 'l2'
+    (the batch core's L2 step and projection, :378-386, as one fused kernel: ``tvc_l2_step``)."""
 
     def __init__(self, config: Optional[HubnessAttackConfig] = None, clip_model=None):
         self.config = config or HubnessAttackConfig()
-        if self.config.norm_constraint != "linf":
-            raise NotImplementedError("only norm_constraint='linf' is built (the reference's default)")
+        if self.config.norm_constraint not in ("linf", "l2"):
+            raise ValueError(f"norm_constraint must be 'linf' or 'l2' (got {self.config.norm_constraint!r})")
         if clip_model is None:
             from .clip import CLIPConfig, CLIPModel
             clip_model = CLIPModel(CLIPConfig(model_name=self.config.clip_model, device=self.config.device))
@@ -351,8 +351,12 @@ class HubnessAttack:
             best_loss = torch.where(better, loss, best_loss)
             best = torch.where(better.view(-1, 1, 1, 1), adv, best)
             grad = self.engine.encode_image_backward(g_out)
-            # :617-637: p -= step * sign(grad); clamp to the eps ball; clamp the image  == one descent pgd_step
-            self.engine.pgd_step(adv, clean, grad, None, c.epsilon, c.step_size, 0.0, c.clamp_min, c.clamp_max, True)
+            if c.norm_constraint == "l2":
+                # :378-386: unit-L2 gradient step, projection onto the eps L2 ball, clamp (descent, as the L-inf form)
+                self.engine.l2_step(adv, clean, grad, c.epsilon, c.step_size, c.clamp_min, c.clamp_max, True)
+            else:
+                # :617-637: p -= step * sign(grad); clamp to the eps ball; clamp the image  == one descent pgd_step
+                self.engine.pgd_step(adv, clean, grad, None, c.epsilon, c.step_size, 0.0, c.clamp_min, c.clamp_max, True)
         return best, best_loss
 
     def _unit_queries(self, queries: Sequence[str]) -> torch.Tensor:

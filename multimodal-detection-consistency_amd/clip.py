@@ -200,6 +200,13 @@ class CLIPModel:
         std = torch.tensor(CLIP_STD).view(3, 1, 1)
         return ((x - mean) / std).contiguous()
 
+    def preprocess_tensor(self, images01: torch.Tensor) -> torch.Tensor:
+        """Device images fp32 [n, 3, H, W] with values in [0, 1] -> [n, 3, S, S]: the same bicubic resize of the short side,
+        centre crop and CLIP mean / std as ``preprocess``, in one HIP kernel (``tvc_preprocess_images``) -- generated
+        references never leave the GPU.  (``preprocess`` works on 8-bit PIL pixels: the two agree to the 8-bit rounding.)"""
+        return self.engine.preprocess_images(images01.to(self.device, torch.float32), self.arch.image_size, CLIP_MEAN, CLIP_STD,
+                                             bicubic=True, keep_aspect=True)
+
     def _images_to_device(self, images):
         if isinstance(images, torch.Tensor):
             x = images if images.dim() == 4 else images.unsqueeze(0)

@@ -22,9 +22,6 @@
 #define ATT_DH 64
 #define ATT_KROW 128     // K image: 64 bf16 per row
 #define ATT_VROW 160     // V image: 64 bf16 + 32 B pad (conflict-free tr reads)
-#ifndef TVC_ATT_ASM_MAX
-#define TVC_ATT_ASM_MAX 0
-#endif
 
 // EXACT: every sequence has exactly MAXT key tiles (fixed-length, non-causal: the vision tower).
 // The per-tile guards become compile-time true, so the 16-key tiles of a query block are
@@ -198,27 +195,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
             }
             float m0 = -INFINITY, m1 = -INFINITY;
-#if TVC_ATT_ASM_MAX
-            // Experiment (measured 350 vs 333 us per ViT-L layer call, i.e. SLOWER, kept for the record): the row
-            // maximum as 2 * MAXT v_max3_f32 in asm -- `fmaxf` makes hipcc canonicalise every MFMA output first
-            // (121 max instructions where 34 do).  hipcc pads no hazards for inline asm, so the MFMA -> VALU-read
-            // wait states are spent explicitly behind a scheduling fence; that fence also stops the compiler
-            // from keeping K fragments in registers across query blocks and from interleaving the maxima with
-            // the second MFMA pass, which costs more than the 87 instructions save.
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m0) : "v"(s[t][0]), "v"(s[t][1]));
-                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m1) : "v"(s[t][2]), "v"(s[t][3]));
-            }
-#else
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 m0 = fmaxf(m0, fmaxf(s[t][0], s[t][1]));
                 m1 = fmaxf(m1, fmaxf(s[t][2], s[t][3]));
             }
-#endif
             mx = fmaxf(m0, m1);
         } else {
 #pragma unroll

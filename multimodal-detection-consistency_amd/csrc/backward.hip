@@ -350,6 +350,52 @@ __global__ __launch_bounds__(1024) void pgd_step_kernel(float* __restrict__ adv,
     }
 }
 
+// ---------------------------------------------------------------------------
+// L2-constrained step (src/attacks/hubness_attack.py:378-386), one workgroup per image:
+//   adv += dir * step * grad / (|grad|_2 + 1e-8);   d = adv - clean;   d *= min(|d|_2, eps) / (|d|_2 + 1e-8)
+//   adv = clamp(clean + d, lo, hi)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void l2_step_kernel(float* __restrict__ adv, const float* __restrict__ clean,
+                                                       const float* __restrict__ grad, int64_t n, float eps, float step,
+                                                       float lo, float hi, float dir) {
+    __shared__ float red[16];
+    const int64_t base = (int64_t)blockIdx.x * n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        return tot;
+    };
+    float s = 0.f;
+    for (int64_t i = t; i < n; i += 1024) { const float g = grad[base + i]; s += g * g; }
+    const float gscale = dir * step / (sqrtf(block_sum(s)) + 1e-8f);
+    float q = 0.f;
+    for (int64_t i = t; i < n; i += 1024) {
+        const float a = adv[base + i] + gscale * grad[base + i];
+        adv[base + i] = a;                       // each element is read back by the thread that wrote it
+        const float d = a - clean[base + i];
+        q += d * d;
+    }
+    const float dn = sqrtf(block_sum(q));
+    const float dscale = fminf(dn, eps) / (dn + 1e-8f);
+    for (int64_t i = t; i < n; i += 1024) {
+        const float c = clean[base + i];
+        adv[base + i] = fminf(fmaxf(c + (adv[base + i] - c) * dscale, lo), hi);
+    }
+}
+
+hipError_t launch_l2_step(float* adv, const float* clean, const float* grad, int B, int64_t n, float eps, float step, float lo,
+                          float hi, int descent, hipStream_t stream) {
+    if (B <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2_step_kernel, dim3(B), dim3(1024), 0, stream, adv, clean, grad, n, eps, step, lo, hi, descent ? -1.0f : 1.0f);
+    return hipGetLastError();
+}
+
 hipError_t launch_pgd_step(float* adv, const float* clean, const float* grad, float* mom, int B, int64_t n, float eps,
                            float alpha, float mu, float lo, float hi, int targeted, hipStream_t stream) {
     if (B <= 0 || n <= 0) return hipSuccess;

@@ -7,12 +7,8 @@
 #include <type_traits>
 
 // s_setprio levels of the MFMA phases of the two wave groups of the ring kernel (see gemm_ring_kernel)
-#ifndef TVC_PRIO_G0
 #define TVC_PRIO_G0 1
-#endif
-#ifndef TVC_PRIO_G1
 #define TVC_PRIO_G1 2
-#endif
 
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmOperands g, GemmEpilogue e,
@@ -35,27 +31,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmOperands g,
 // ---------------------------------------------------------------------------
 // Persistent ring-pipelined variant (gemm_ring.hpp): used for the big tower GEMMs.
 // ---------------------------------------------------------------------------
-#ifdef TVC_RING_STAMPS
-// diagnostic build only (scripts/ring_stamps.py): per-wave shader-clock totals of the loop phases
-__device__ unsigned long long ring_stamps[256 * 8 * 8];
-extern "C" int tvc_debug_ring_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_stamps), sizeof(ring_stamps));
-}
-__device__ unsigned long long ring_trace[4 * 512];
-// form 4: per wave {first K-tile of a tile, other K-tiles, epilogue issue, barrier after / before the epilogue}
-__device__ unsigned long long ring4_tile_stamps[256 * 8 * 4];
-extern "C" int tvc_debug_ring4_tile_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring4_tile_stamps), sizeof(ring4_tile_stamps));
-}
-extern "C" int tvc_debug_ring_trace(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ring_trace), sizeof(ring_trace));
-}
-#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; \
-                   if ((i) == 5 && S < 512 && lane == 0 && (blockIdx.x == 8 || blockIdx.x == 100) && (wave & 3) == 0) \
-                       ring_trace[((blockIdx.x == 100) * 2 + (wave >> 2)) * 512 + S] = t_; }
-#else
-#define STAMP(i)
-#endif
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,20 +46,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     const int total = my_tiles * nk;                               // stages in this workgroup's stream
     if (total == 0) return;
 
-#ifdef TVC_RING_STAGGER
-    // XCD x starts x/8 of a tile period late: the tile epilogues (a 4 MiB dirty burst per XCD) of
-    // different XCDs no longer hit HBM at the same time
-    for (int i = (blockIdx.x & 7) * nk * TVC_RING_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(1);
-#endif
     const uint32_t smem_lds = lds_addr(smem);
     // ---- issue side: scalar tile bases + per-lane 32-bit offsets (recomputed per tile only)
     int is_tile = 0, is_p = 0, is_kk = 0, is_n = 0;
     const char* is_abase; const char* is_bbase;
     uint32_t va[2], vb[2];
     auto issue_tile = [&](int lin) {
-#ifdef TVC_RING_ALIAS
-        lin %= TVC_RING_ALIAS;       // diagnostic build only: every workgroup re-reads the first few tiles' operands (L2-resident)
-#endif
         const int jt = lin / nIt;
         const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
         is_abase = (const char*)(g.A + (int64_t)i0 * g.lda);
@@ -195,14 +162,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
         asm volatile("" ::: "memory");
     };
 
-#ifdef TVC_RING_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#endif
     if (gid == 0) {
         int it = 0, iks = 0;     // tile / k-stage of the stage being loaded (== multiplied) this interval
         for (int S = 0; S < total; ++S) {
-            STAMP(0)
             if (S + 3 < total) issue();
             if (iks == 0 && wave == 0 && e.bias) {
                 // the tile's 256 bias values -> one of TWO alternating LDS slots (group 1 may still be
@@ -213,456 +175,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
                 if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (it & 1) * 1024);
             }
             if (++iks == nk) { iks = 0; ++it; }
-            STAMP(1)
             load_frags(S);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(2)
             mfma_stage(std::integral_constant<int, TVC_PRIO_G0>{});
-            STAMP(3)
             finish_stage(3);
-            STAMP(4)
             retire_and_barrier(S);
-            STAMP(5)
         }
     } else {
         for (int S = 0; S < total; ++S) {
-            STAMP(0)
-            if (S > 0) { mfma_stage(std::integral_constant<int, TVC_PRIO_G1>{}); STAMP(3) finish_stage(2); STAMP(4) }
+            if (S > 0) { mfma_stage(std::integral_constant<int, TVC_PRIO_G1>{}); finish_stage(2); }
             if (S + 3 < total) issue();
-            STAMP(1)
             load_frags(S);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(2)
             retire_and_barrier(S);
-            STAMP(5)
         }
         mfma_stage(std::integral_constant<int, TVC_PRIO_G1>{});
         finish_stage(0);
     }
-#ifdef TVC_RING_STAMPS
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) ring_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i];
-#endif
-}
-
-
-// ---------------------------------------------------------------------------
-// Ring main loop, second form: fragments PREFETCHED one stage ahead (two named register sets).
-//
-// In-kernel stamps of gemm_ring_kernel (scripts/ring_stamps.py) put one stage of one wave at
-//   loop bookkeeping 196 + LDS-DMA issue 352 + ds_read + wait 231 + MFMA 665 + barrier wait 355 = 1873 clk (FC2)
-// for 2 x 512 clk of matrix-pipe work per SIMD: the interval is the SERIAL sum of a wave's own phases (each wave
-// runs load -> wait -> multiply in order), not the matrix pipe.  Here the fragments of stage S+1 are read while
-// stage S multiplies (the kernel had 53 free VGPRs: a second a[8] / b[4] set costs 48), so the ds_read latency
-// leaves the serial chain, the LDS-DMA of stage S+4 is issued first and the bookkeeping is incremental.
-//   ring protocol (4 slots, stage S in slot S % 4):
-//     interval S:  issue stage S+4 into slot S % 4 (stage S's fragments were read in interval S-1, every wave's
-//                  lgkmcnt(0) precedes the barrier that ended it);  read the fragments of stage S+1;  multiply
-//                  stage S;  retire: stage S+2 must have landed before interval S+1 reads it, i.e. at most the
-//                  pieces of stages S+3, S+4 (+ a tile epilogue's stores) stay in flight: vmcnt(8 / 24 / 40).
-//   The two waves of a SIMD still run the phases in opposite order (group 0: issue, read, multiply; group 1:
-//   multiply, issue, read) so that one feeds the matrix pipe while the other sits in LDS-DMA issue.
-// ---------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring2_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int kpp = g.ksteps_per_plane * (GEMM_BK / RING_BK);     // 32-deep stages per plane
-    const int nk = g.planes * kpp;                                 // stages per tile (even: K % 64 == 0)
-
-    RingSchedule sch;
-    sch.init(nIt * nJt);
-    const int my_tiles = sch.count();
-    const int total = my_tiles * nk;                               // stages in this workgroup's stream (even)
-    if (total == 0) return;
-
-    const uint32_t smem_lds = lds_addr(smem);
-    // ---- issue side: running scalar pointers of the next stage, per-lane 32-bit offsets per tile
-    int is_tile = 0, is_p = 0, is_kk = 0, is_n = 0;
-    const char* is_abase; const char* is_bbase;       // tile bases
-    const char* is_ap; const char* is_bp;             // next stage of the current plane
-    uint32_t va[2], vb[2];
-    auto issue_tile = [&](int lin) __attribute__((always_inline)) {
-#ifdef TVC_RING_ALIAS
-        lin %= TVC_RING_ALIAS;
-#endif
-        const int jt = lin / nIt;
-        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
-        is_abase = (const char*)(g.A + (int64_t)i0 * g.lda);
-        is_bbase = (const char*)(g.B + (int64_t)j0 * g.ldb);
-        is_ap = is_abase + (int64_t)g.a_plane_off[0] * 2;
-        is_bp = is_bbase + (int64_t)g.b_plane_off[0] * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wave * 32 + i * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ (3 * ((r >> 3) & 1));
-            int ra = r, rb = r;
-            if (i0 + ra >= g.I) ra = g.I - 1 - i0;
-            if (j0 + rb >= g.J) rb = g.J - 1 - j0;
-            va[i] = (uint32_t)ra * (uint32_t)(g.lda * 2) + c * 16;
-            vb[i] = (uint32_t)rb * (uint32_t)(g.ldb * 2) + c * 16;
-        }
-    };
-    issue_tile(sch.tile(0));
-    auto issue = [&]() __attribute__((always_inline)) {
-        const uint32_t slot = smem_lds + (is_n & (RING_SLOTS - 1)) * RING_SLOT_BYTES + wave * (32 * 64);
-        glds16x4_asm(is_ap, va[0], va[1], slot, is_bp, vb[0], vb[1], slot + RING_HALF_BYTES);
-        ++is_n;
-        is_ap += RING_BK * 2; is_bp += RING_BK * 2;
-        if (++is_kk == kpp) {
-            is_kk = 0;
-            if (++is_p == g.planes) {
-                is_p = 0;
-                if (++is_tile < my_tiles) issue_tile(sch.tile(is_tile));
-            } else {
-                is_ap = is_abase + (int64_t)g.a_plane_off[is_p] * 2;
-                is_bp = is_bbase + (int64_t)g.b_plane_off[is_p] * 2;
-            }
-        }
-    };
-
-    const int pos = ((lane >> 4) ^ (3 * ((lane >> 3) & 1))) * 16;
-    const int a_off = (wm * 128 + (lane & 15)) * 64 + pos;
-    const int b_off = RING_HALF_BYTES + (wn * 64 + (lane & 15)) * 64 + pos;
-    const int gid = wave >> 2;
-
-    gemm_acc_t acc;
-    gemm_zero_acc(acc);
-    bf16x8_t a0[8], b0[4], a1[8], b1[4];
-    int credit = 0;
-    const bool st16 = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) && (e.ldo & 7) == 0;
-    int ct = 0, cks = 0;
-
-    auto tile_origin = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
-        const int lin = sch.tile(t);
-        const int jt = lin / nIt;
-        i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
-    };
-    auto load_frags = [&](int S, bf16x8_t (&a)[8], bf16x8_t (&b)[4]) __attribute__((always_inline)) {
-        const char* slot = smem + (S & (RING_SLOTS - 1)) * RING_SLOT_BYTES;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a[m] = *(const bf16x8_t*)(slot + a_off + m * 1024);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = *(const bf16x8_t*)(slot + b_off + n * 1024);
-    };
-    // MFMA phase priorities: the trailing group's phase runs at the higher priority (see gemm_ring_kernel)
-#define RING2_MFMA(A_, B_)                                                                            \
-    {                                                                                                 \
-        if (gid == 0) __builtin_amdgcn_s_setprio(TVC_PRIO_G0); else __builtin_amdgcn_s_setprio(TVC_PRIO_G1); \
-        _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                 \
-            _Pragma("unroll") for (int n = 0; n < 4; ++n)                                             \
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[m], B_[n], acc[m][n], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                \
-    }
-    // stage S+2 must have landed (it is read in interval S+1); younger stages issued so far: up to S+4
-    auto retire_and_barrier = [&](int S) __attribute__((always_inline)) {
-        const int last = (S + 4 < total ? S + 4 : total - 1);
-        const int n_out = last - (S + 2);                                     // stages that may stay in flight
-        // lgkmcnt(0) through the BUILTIN: hipcc's waitcnt pass then knows that the fragment set read in this
-        // interval is complete and does not guard the next interval's MFMAs with waits for the (younger)
-        // prefetch reads; the LDS-DMA pieces are invisible to it, their counted vmcnt stays inline asm
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (n_out >= 2 && credit > 0 && st16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (n_out >= 2 && credit > 0) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        else if (n_out >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (n_out == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (credit > 0) --credit;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    // ---- prologue: stages 0..3 in flight, stage 0's fragments in set 0, stage 1 landed
-    for (int s = 0; s < 4 && s < total; ++s) issue();
-    if (total >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // stage 0 (own pieces)
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                       // total == 2
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_frags(0, a0, b0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (total >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 1
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int it = 0, iks = 0;         // tile / k-stage of the stage multiplied in the current interval (bias staging)
-    auto stage_bias = [&]() __attribute__((always_inline)) {
-        if (iks == 0 && wave == 0 && e.bias) {
-            // the tile's 256 bias values -> one of TWO alternating LDS slots (the partner group may still be in
-            // the previous tile's epilogue, reading the other slot); retired by this wave's counted waits long
-            // before the epilogue (>= 8 stages follow)
-            int i0, j0;
-            tile_origin(it, i0, j0);
-            if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + RING_LDS_BYTES + (it & 1) * 1024);
-        }
-        if (++iks == nk) { iks = 0; ++it; }
-    };
-    // Two intervals per iteration (static register sets).  A tile has an even number of stages, so only the
-    // SECOND interval of a pair can end a tile: one epilogue site, shared by both wave groups.
-    for (int S = 0; S < total; S += 2) {
-        // ---- interval S: multiply set 0, prefetch stage S+1 into set 1
-        if (gid == 0) {
-            if (S + 4 < total) issue();
-            stage_bias();
-            load_frags(S + 1, a1, b1);
-        }
-        RING2_MFMA(a0, b0)
-        ++cks;
-        if (gid != 0) {
-            if (S + 4 < total) issue();
-            load_frags(S + 1, a1, b1);
-        }
-        retire_and_barrier(S);
-        // ---- interval S+1: multiply set 1, prefetch stage S+2 into set 0
-        if (gid == 0) {
-            if (S + 5 < total) issue();
-            stage_bias();
-            if (S + 2 < total) load_frags(S + 2, a0, b0);
-        }
-        RING2_MFMA(a1, b1)
-        if (++cks == nk) {
-            int i0, j0;
-            tile_origin(ct, i0, j0);
-            gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES + (ct & 1) * 1024);
-            gemm_zero_acc(acc);
-            const bool fast = (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J) && ((e.ldo & 3) == 0);
-            credit = fast ? (gid == 0 ? 3 : 2) : 0;
-            cks = 0; ++ct;
-        }
-        if (gid != 0) {
-            if (S + 5 < total) issue();
-            if (S + 2 < total) load_frags(S + 2, a0, b0);
-        }
-        retire_and_barrier(S + 1);
-    }
-#undef RING2_MFMA
-}
-
-
-// ---------------------------------------------------------------------------
-// Ring main loop, third form: 64-deep K-tiles, so that every LDS-DMA piece reads WHOLE 128-byte lines.
-//
-// scripts/ubench/dma_rate.hip (LDS-DMA alone, L2-resident source, 8 waves x 4 pieces per stage): pieces of
-// 16 rows x 64 B (what a 32-deep stage reads) fill LDS at 29-32 B/clk/CU, pieces of 8 rows x 128 B at 58-60:
-// the line is fetched whole either way and half of it is thrown away.  A 32-deep stage of the forms above
-// therefore costs the load path twice its bytes, and that -- not the matrix pipe, which PMC counters show 45 %
-// busy -- sets their stage interval (prefetching the fragments, form 2, changed nothing).
-//   LDS: 2 slots x (A [256][64] 32 KiB + B [256][64] 32 KiB); images as gemm_core.hpp (128-byte rows, 16-byte
-//   chunk c of row r at chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128, swizzle on the SOURCE address).
-//   A K-tile is multiplied in two 32-deep steps; fragments are prefetched one step ahead (two register sets).
-//     interval (t, 0): read fragments (t, 1);  multiply (t, 0);  retire K-tile t+1 (vmcnt: only a tile
-//                      epilogue's stores may stay in flight);  barrier  -> slot t % 2 is free, t+1 is visible
-//     interval (t, 1): issue K-tile t+2 into slot t % 2;  read fragments (t+1, 0);  multiply (t, 1);  tile
-//                      epilogue after the last K-tile of a tile;  no wait, no barrier needed for the ring
-//   K-tile t+2 is in flight during (t, 1) and (t+1, 0): two intervals for 64 KiB.
-// ---------------------------------------------------------------------------
-
-// four 1-KiB pieces (8 rows x 128 B each) of one operand: one M0 save / restore
-__device__ __forceinline__ void glds16_rows4_asm(const void* base, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3,
-                                                 uint32_t lds) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(lds)
-                 : "memory", "scc");
-}
-
-#ifndef TVC_R3_ODD_BARRIER
-#define TVC_R3_ODD_BARRIER 1
-#endif
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring3_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int gid = wave >> 2;
-    const int kpp = g.ksteps_per_plane;                            // 64-deep K-tiles per plane
-    const int nkt = g.planes * kpp;                                // K-tiles per output tile
-
-    RingSchedule sch;
-    sch.init(nIt * nJt);
-    const int my_tiles = sch.count();
-    const int T = my_tiles * nkt;                                  // K-tiles in this workgroup's stream
-    if (T == 0) return;
-
-    const uint32_t smem_lds = lds_addr(smem);
-    // ---- issue side.  No row clamping here: the launcher guarantees I % 256 == 0 and that B has readable rows up
-    // to the next multiple of 256 (rows >= J are garbage that only reaches output columns that are never stored).
-    // Piece i of a wave covers rows wave*32 + 8 i + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7):
-    // the swizzle term alternates between two values with the parity of i, the row term is a scalar step, so two
-    // lane offsets per operand stay live across the loop and the four addresses are formed when issuing.
-    struct Cursor { int tile, p, kk, n; const char* abase; const char* bbase; const char* ap; const char* bp; };
-    const uint32_t a_rs = (uint32_t)(g.lda * 16), b_rs = (uint32_t)(g.ldb * 16);     // 8 rows, bytes
-    // Lane-constant offsets are RECOMPUTED where they are used (from an opaque copy of the lane index, so that
-    // hipcc neither hoists nor keeps them): the loop runs at the 256-register limit, and ONE spilled value makes
-    // the compiler guard the loop with s_waitcnt vmcnt(0) for its scratch reloads -- draining the LDS-DMA ring.
-    auto opaque_lane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto cur_tile = [&](Cursor& c, int lin) __attribute__((always_inline)) {
-#ifdef TVC_RING_ALIAS
-        lin %= TVC_RING_ALIAS;
-#endif
-        const int jt = lin / nIt;
-        const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
-        c.abase = (const char*)(g.A + (int64_t)i0 * g.lda);
-        c.bbase = (const char*)(g.B + (int64_t)j0 * g.ldb);
-        c.ap = c.abase + (int64_t)g.a_plane_off[0] * 2;
-        c.bp = c.bbase + (int64_t)g.b_plane_off[0] * 2;
-    };
-    auto cur_advance = [&](Cursor& c) __attribute__((always_inline)) {
-        ++c.n;
-        c.ap += GEMM_BK * 2; c.bp += GEMM_BK * 2;
-        if (++c.kk == kpp) {
-            c.kk = 0;
-            if (++c.p == g.planes) {
-                c.p = 0;
-                if (++c.tile < my_tiles) cur_tile(c, sch.tile(c.tile));
-            } else {
-                c.ap = c.abase + (int64_t)g.a_plane_off[c.p] * 2;
-                c.bp = c.bbase + (int64_t)g.b_plane_off[c.p] * 2;
-            }
-        }
-    };
-    Cursor is{0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
-    cur_tile(is, sch.tile(0));
-    auto issue = [&]() __attribute__((always_inline)) {
-        const uint32_t slot = smem_lds + (is.n & 1) * R3_SLOT_BYTES + wave * (32 * 128);
-        const int l = opaque_lane();
-        const int r0 = wave * 32 + (l >> 3);
-        const int c0 = (l & 7) ^ ((r0 >> 1) & 7);
-        const uint32_t va_e = (uint32_t)r0 * (uint32_t)(g.lda * 2) + c0 * 16;
-        const uint32_t vb_e = (uint32_t)r0 * (uint32_t)(g.ldb * 2) + c0 * 16;
-#ifndef TVC_R3_NO_DMA            // (ablation builds only)
-        glds16_rows4_asm(is.ap, va_e, (va_e ^ 64) + a_rs, va_e + 2 * a_rs, (va_e ^ 64) + 3 * a_rs, slot);
-        glds16_rows4_asm(is.bp, vb_e, (vb_e ^ 64) + b_rs, vb_e + 2 * b_rs, (vb_e ^ 64) + 3 * b_rs, slot + GEMM_TILE_BYTES);
-#endif
-        cur_advance(is);
-    };
-
-    // k-sub-step 1 = chunk + 4 = the same address with bit 6 flipped (the swizzle XORs the chunk's low bits only)
-
-    gemm_acc_t acc;
-    gemm_zero_acc(acc);
-    bf16x8_t a0[8], b0[4], a1[8], b1[4];
-    bool credit = false;         // a fast epilogue's stores are the youngest entries of the queue at the next retire
-    const bool st16 = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) && (e.ldo & 7) == 0;
-    int ct = 0, ckt = 0;         // output tile / K-tile inside it of the K-tile being multiplied
-
-    auto tile_origin = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
-        const int lin = sch.tile(t);
-        const int jt = lin / nIt;
-        i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
-    };
-    auto load_frags = [&](int t, int ks, bf16x8_t (&a)[8], bf16x8_t (&b)[4]) __attribute__((always_inline)) {
-        // ONE address register per operand, the sub-tiles are immediate offsets
-        const int l = opaque_lane();
-        const int sw0 = ((0 + (l >> 4)) ^ ((l >> 1) & 7)) * 16;
-        const uint32_t a_rd = smem_lds + (wm * 128 + (l & 15)) * 128 + sw0;
-        const uint32_t b_rd = smem_lds + GEMM_TILE_BYTES + (wn * 64 + (l & 15)) * 128 + sw0;
-        const uint32_t so = (t & 1) * R3_SLOT_BYTES;
-        const __attribute__((address_space(3))) char* pa = (const __attribute__((address_space(3))) char*)(uintptr_t)((a_rd ^ (ks * 64)) + so);
-        const __attribute__((address_space(3))) char* pb = (const __attribute__((address_space(3))) char*)(uintptr_t)((b_rd ^ (ks * 64)) + so);
-#ifdef TVC_R3_NO_DSREAD          // (ablation builds only: fragments keep whatever they hold, kept alive)
-#pragma unroll
-        for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(a[m]));
-#pragma unroll
-        for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(b[n]));
-        return;
-#endif
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a[m] = *(const __attribute__((address_space(3))) bf16x8_t*)(pa + m * 2048);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = *(const __attribute__((address_space(3))) bf16x8_t*)(pb + n * 2048);
-    };
-#ifdef TVC_R3_NO_MFMA
-#define RING3_MFMA(A_, B_) { _Pragma("unroll") for (int m = 0; m < 8; ++m) asm volatile("" :: "v"(A_[m])); _Pragma("unroll") for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(B_[n])); }
-#else
-#define RING3_MFMA(A_, B_)                                                                            \
-    {                                                                                                 \
-        if (gid == 0) __builtin_amdgcn_s_setprio(TVC_PRIO_G0); else __builtin_amdgcn_s_setprio(TVC_PRIO_G1); \
-        _Pragma("unroll") for (int m = 0; m < 8; ++m)                                                 \
-            _Pragma("unroll") for (int n = 0; n < 4; ++n)                                             \
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[m], B_[n], acc[m][n], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                \
-    }
-#endif
-
-    // ---- prologue: K-tiles 0 and 1 in flight, fragments (0, 0) in set 0
-    issue();
-    if (T > 1) issue();
-    if (T > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_frags(0, 0, a0, b0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-
-    for (int t = 0; t < T; ++t) {
-        // ================= interval (t, 0): multiply set 0, prefetch (t, 1) into set 1
-        if (gid == 0) {
-            if (ckt == 0 && wave == 0 && e.bias) {
-                // the tile's 256 bias values -> one of two alternating 1-KiB LDS slots (the other group may still
-                // be in the previous tile's epilogue); landed long before this tile's epilogue
-                int i0, j0;
-                tile_origin(ct, i0, j0);
-                if (i0 + GEMM_BM <= g.I) glds16_asm(e.bias + i0, lane * 16, smem_lds + R3_LDS_BYTES + (ct & 1) * 1024);
-            }
-            load_frags(t, 1, a1, b1);
-        }
-        RING3_MFMA(a0, b0)
-        if (gid != 0) load_frags(t, 1, a1, b1);
-        // retire: K-tile t+1 (issued in interval (t-1, 1)) must have landed; only a tile epilogue's stores and this
-        // wave's bias piece are younger
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (credit && st16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (credit) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        credit = false;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ================= interval (t, 1): multiply set 1, issue K-tile t+2, prefetch (t+1, 0) into set 0
-        // (at a tile's last K-tile the prefetch waits until the epilogue is through: its temporaries and a
-        // second live fragment set do not fit the 256-register budget together)
-        const bool tile_end = (ckt + 1 == nkt);
-        if (gid == 0) {
-            if (t + 2 < T) issue();
-            if (!tile_end && t + 1 < T) load_frags(t + 1, 0, a0, b0);
-        }
-        RING3_MFMA(a1, b1)
-        if (gid != 0) {
-            if (t + 2 < T) issue();
-            if (!tile_end && t + 1 < T) load_frags(t + 1, 0, a0, b0);
-        }
-        if (tile_end) {
-            int i0, j0;
-            tile_origin(ct, i0, j0);
-            // an opaque copy of the lane index: hipcc would otherwise hoist the epilogue's lane-dependent 64-bit
-            // address parts out of the K loop, keep ~10 registers live across it and SPILL them -- and a scratch
-            // reload anywhere in the loop makes its waitcnt pass guard the loop header with vmcnt(0), which
-            // drains the LDS-DMA ring every interval
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
-            gemm_zero_acc(acc);
-            credit = (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J) && ((e.ldo & 3) == 0);
-            ckt = 0; ++ct;
-            if (t + 1 < T) load_frags(t + 1, 0, a0, b0);
-        } else {
-            ++ckt;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-#if TVC_R3_ODD_BARRIER
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#endif
-    }
-#undef RING3_MFMA
 }
 
 
@@ -754,9 +283,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         const int row = isA ? rA[q] : rB[q];
         const char* base = (isA ? is.ap : is.bp) + (uint32_t)row * (isA ? pitchA : pitchB);
         const uint32_t dst = buf_issue + (isA ? 0 : GEMM_TILE_BYTES) + row * 128;
-#ifndef TVC_R4_NO_DMA            // (ablation builds only)
         if (isA) glds16_rows2_asm(base, vA0, vA1, dst); else glds16_rows2_asm(base, vB0, vB1, dst);
-#endif
         if (kind == 3) { buf_issue = (buf_issue == smem_lds) ? smem_lds + R3_SLOT_BYTES : smem_lds; cur_advance(is); }
     };
     using U_A0 = std::integral_constant<int, 0>; using U_B0 = std::integral_constant<int, 1>;
@@ -796,9 +323,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
             b[n][1] = *(lds_frag_p)(uintptr_t)(r1 + n * 2048);
         }
     };
-#ifdef TVC_R4_NO_MFMA            // (ablation builds only: the fragments are consumed, nothing is multiplied)
-#define RING4_MFMA(A_, B_, QA_, QB_) { _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(A_[m][ks])); _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) asm volatile("" :: "v"(B_[n][ks])); }
-#else
 #define RING4_MFMA(A_, B_, QA_, QB_)                                                                              \
     {                                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                            \
@@ -809,7 +333,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
                         A_[m][ks], B_[n][ks], acc[(QA_) * 4 + m][(QB_) * 2 + n], 0, 0, 0);                        \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     }
-#endif
 #define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
 #define RING4_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -874,23 +397,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     const bool credit_ok = (EPI_STORES == 32) ? ((e.ldo & 3) == 0) : ((e.ldo & 7) == 0);
     bool credit = false;
     int t = 0;
-#ifdef TVC_RING_STAMPS
-    unsigned long long ts_first = 0, ts_rest = 0, ts_epi = 0, ts_bar = 0, ts_last = __builtin_amdgcn_s_memtime();
-#define R4T(acc_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_ += t_ - ts_last; ts_last = t_; }
-#else
-#define R4T(acc_)
-#endif
 #pragma unroll 1
     for (ct = 0; ct < my_tiles; ++ct) {
         if (credit) ktile(t, CE{}); else ktile(t, C0{});
         ++t;
-        R4T(ts_first)
 #pragma unroll 1
         for (int k = 1; k < nkt; ++k, ++t) {
             RING4_BARRIER()
             ktile(t, C0{});
         }
-        R4T(ts_rest)
         // the NEXT tile's bias slice goes into the queue ahead of this tile's stores: with it there, wave 0's credited
         // waits ask for one OLDER load more, never for a store
         if (ct + 1 < my_tiles) stage_bias(ct + 1);
@@ -902,29 +417,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         auto tile_end = [&]() __attribute__((always_inline)) {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
-#if defined(TVC_R4_NO_EPI)            // (ablation builds only: the sums are consumed, nothing is stored)
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(acc[m][n]));
-#else
             gemm_tile_epilogue<EPI, true, 4, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
-#endif
         };
-        if (wm == 1) { tile_end(); R4T(ts_epi) }
+        if (wm == 1) { tile_end(); }
         RING4_BARRIER()
-        R4T(ts_bar)
-        if (wm == 0) { tile_end(); R4T(ts_epi) }
+        if (wm == 0) { tile_end(); }
         gemm_zero_acc(acc);
         credit = credit_ok && (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J);
     }
-#ifdef TVC_RING_STAMPS
-    if (lane == 0) {
-        unsigned long long* o = ring4_tile_stamps + (blockIdx.x * 8 + wave) * 4;
-        o[0] = ts_first; o[1] = ts_rest; o[2] = ts_epi; o[3] = ts_bar;
-    }
-#endif
-#undef R4T
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stream's overrun stages must have landed before the LDS is given back
     if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
 #undef RING4_MFMA
@@ -1004,15 +504,9 @@ static hipError_t set_lds_attr_impl() {
     SET_ATTR(gemm_ring_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring_kernel<TVC_EPI_GELU_BF16>)
     SET_ATTR(gemm_ring_kernel<TVC_EPI_RESID_F32>)
-    SET_ATTR(gemm_ring3_kernel<TVC_EPI_F32>)
-    SET_ATTR(gemm_ring3_kernel<TVC_EPI_BF16>)
-    SET_ATTR(gemm_ring3_kernel<TVC_EPI_GELU_BF16>)
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_F32>)
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_GELU_BF16>)
-    SET_ATTR(gemm_ring2_kernel<TVC_EPI_F32>)
-    SET_ATTR(gemm_ring2_kernel<TVC_EPI_BF16>)
-    SET_ATTR(gemm_ring2_kernel<TVC_EPI_GELU_BF16>)
 #undef SET_ATTR
     return st;
 }
@@ -1029,7 +523,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     e.bias = L.bias; e.out = L.out; e.ldo = L.ldo;
     const int nIt = (L.I + GEMM_BM - 1) / GEMM_BM, nJt = (L.J + GEMM_BN - 1) / GEMM_BN;
     const dim3 block(GEMM_THREADS);
-    // variant: 0 = one tile per workgroup (gemm_core.hpp), 1 = persistent ring (gemm_ring.hpp).
+    // variant: 0 = one tile per workgroup (gemm_core.hpp), 1 = persistent ring (gemm_ring.hpp / gemm_ring4.hpp).
     // The ring needs enough tiles to keep 256 persistent workgroups busy.
     static const int forced = [] { const char* v = getenv("TVC_GEMM_VARIANT"); return v ? atoi(v) : -1; }();
     const int ntiles = nIt * nJt;
@@ -1038,24 +532,6 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     // tiles than CUs, one tile per workgroup: TVC_GEMM_RING_MIN_TILES, default 64)
     static const int ring_min = [] { const char* v = getenv("TVC_GEMM_RING_MIN_TILES"); return v ? atoi(v) : 64; }();
     const bool ring = deep && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= ring_min));
-    // the four-wave kernel takes whole tiles, bf16 outputs and an even stage count; a ragged
-    // remainder of token rows is a second launch on the eight-wave kernels
-    const bool solo_ok = (L.epilogue == TVC_EPI_BF16 || L.epilogue == TVC_EPI_GELU_BF16) && L.I % GEMM_BM == 0 &&
-                         L.ldo % 8 == 0 && (((int64_t)L.K * L.planes / RING_BK) % 2 == 0) && !L.no_solo;
-    const int Jf = L.J / GEMM_BN * GEMM_BN;
-    const bool solo = deep && solo_ok && (forced >= 0 ? (forced == 2 && nIt * (Jf / GEMM_BN) >= 8)
-                                                       : false);
-    if (solo) {
-        g.J = Jf;
-        hipError_t st2 = launch_gemm_solo(g, e, L.epilogue, nIt, Jf / GEMM_BN, stream);
-        if (st2 != hipSuccess || Jf == L.J) return st2;
-        GemmLaunch R = L;
-        R.B = L.B + (int64_t)Jf * L.ldb;
-        R.out = (char*)L.out + (int64_t)Jf * L.ldo * 2;       // bf16 outputs
-        R.J = L.J - Jf;
-        R.no_solo = true;
-        return launch_gemm_bf16(R, stream);
-    }
     if (ring) {
         // ---- split-K tail: whole rounds to the ring kernel, the left-over tile columns split over K
         // Opt-in (TVC_GEMM_SPLITK_TAIL=1): it shortens the GEMM launches themselves by 1.4 % (89.7 vs 91.0 ms
@@ -1100,9 +576,11 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         }
         const dim3 rgrid(ntiles >= 256 ? 256 : (ntiles + 7) / 8 * 8);   // a workgroup without a tile returns at once
         // ring form: 4 (barrier-staggered ping-pong in 16-MFMA phases over 64-deep whole-line K-tiles) where its
-        // preconditions hold (they are form 3's), else 1; TVC_GEMM_RING_FORM=1|2|3|4 forces one (experiments)
+        // preconditions hold, else 1 (32-deep stages, clamped rows: any shape); TVC_GEMM_RING_FORM=1 forces form 1.
+        // (Forms 2 and 3 and the four-wave gemm_solo kernel of rounds 1-2 measured no faster than these two and were
+        // removed in round 3; DESIGN.md 4.1 keeps their numbers.)
         static const int ring_form = [] { const char* v = getenv("TVC_GEMM_RING_FORM"); return v ? atoi(v) : 4; }();
-        // form 3 reads whole rows without clamping: out-feature rows must fill whole tiles, B must have readable
+        // form 4 reads whole rows without clamping: out-feature rows must fill whole tiles, B must have readable
         // rows up to the next multiple of 256 (J % 256 == 0, or a padded workspace: GemmLaunch::b_rows_padded), and
         // the row pitches must be multiples of 128 bytes (its source swizzle flips address bit 6)
         if (ring_form == 4 && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
@@ -1116,39 +594,6 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
                     break;
                 case TVC_EPI_GELU_BF16:
                     hipLaunchKernelGGL(gemm_ring4_kernel<TVC_EPI_GELU_BF16>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
-                    break;
-                default:
-                    return hipErrorInvalidValue;
-            }
-            return hipGetLastError();
-        }
-        if ((ring_form == 3 || ring_form == 4) && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
-            (L.J % GEMM_BN == 0 || L.b_rows_padded) && L.lda % 64 == 0 && L.ldb % 64 == 0) {
-            switch (L.epilogue) {
-                case TVC_EPI_F32:
-                    hipLaunchKernelGGL(gemm_ring3_kernel<TVC_EPI_F32>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
-                    break;
-                case TVC_EPI_BF16:
-                    hipLaunchKernelGGL(gemm_ring3_kernel<TVC_EPI_BF16>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
-                    break;
-                case TVC_EPI_GELU_BF16:
-                    hipLaunchKernelGGL(gemm_ring3_kernel<TVC_EPI_GELU_BF16>, rgrid, block, R3_LDS_BYTES + 4096, stream, g, e, nIt, nJt);
-                    break;
-                default:
-                    return hipErrorInvalidValue;
-            }
-            return hipGetLastError();
-        }
-        if (ring_form == 2 && L.epilogue != TVC_EPI_RESID_F32) {       // (the read-modify-write epilogue spills in this form)
-            switch (L.epilogue) {
-                case TVC_EPI_F32:
-                    hipLaunchKernelGGL(gemm_ring2_kernel<TVC_EPI_F32>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
-                    break;
-                case TVC_EPI_BF16:
-                    hipLaunchKernelGGL(gemm_ring2_kernel<TVC_EPI_BF16>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
-                    break;
-                case TVC_EPI_GELU_BF16:
-                    hipLaunchKernelGGL(gemm_ring2_kernel<TVC_EPI_GELU_BF16>, rgrid, block, RING_LDS_BYTES + 2048, stream, g, e, nIt, nJt);
                     break;
                 default:
                     return hipErrorInvalidValue;

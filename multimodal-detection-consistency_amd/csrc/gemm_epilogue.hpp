@@ -9,10 +9,6 @@ struct GemmEpilogue {
     int64_t ldo;
 };
 
-// gemm_solo.hip
-hipError_t launch_gemm_solo(const GemmOperands& g, const GemmEpilogue& e, int epilogue, int nIt, int nJt,
-                            hipStream_t stream);
-
 __device__ __forceinline__ float quick_gelu(float x) {
     // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): v_exp_f32 + v_rcp_f32 (1 ulp each; the
     // result is rounded to bf16 anyway) instead of an IEEE division.  x -> -inf: 2^(+inf) = inf,
@@ -140,13 +136,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(const f32x4_t (&acc)[8][NT], 
                     o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                     // (a non-temporal store is 1-3 % faster for this kernel alone and 3.5 % slower for the
                     // layer chain: the next kernel reads these rows back out of L2 / Infinity Cache)
-#ifdef TVC_EPI_NO_STORE                 // (ablation builds only: everything but the store instruction)
-                    asm volatile("" :: "v"(o), "v"(p));
-#elif defined(TVC_EPI_LINEAR_STORE)     // (ablation builds only, WRONG results: every store instruction covers 8 whole lines)
-                    *(u32x4_t*)((uint16_t*)e.out + (int64_t)(j0 + wn * 64 + n * 16 + mp * 4 + (lane >> 4)) * e.ldo + i0 + wm * 128 + (lane & 15) * 8) = o;
-#else
                     *(u32x4_t*)(p + mp * 32) = o;
-#endif
                 }
             } else {
                 uint16_t* p = (uint16_t*)e.out + (int64_t)j * e.ldo + i0 + il;

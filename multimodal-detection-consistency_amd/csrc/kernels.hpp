@@ -133,6 +133,8 @@ hipError_t launch_col2im(const float* dcols, float* dpix, int B, int S, int patc
 hipError_t launch_transpose_bf16(const uint16_t* in, uint16_t* out, int R, int C, hipStream_t stream);
 hipError_t launch_pgd_step(float* adv, const float* clean, const float* grad, float* mom, int B, int64_t n, float eps,
                            float alpha, float mu, float lo, float hi, int targeted, hipStream_t stream);
+hipError_t launch_l2_step(float* adv, const float* clean, const float* grad, int B, int64_t n, float eps, float step, float lo,
+                          float hi, int descent, hipStream_t stream);
 hipError_t launch_attention_bwd(const uint16_t* qkv, const uint16_t* dao, uint16_t* dqkv, float* stats_ws, int n_seq, int T,
                                 int heads, hipStream_t stream);
 
@@ -168,3 +170,5 @@ hipError_t sd_timestep_embed(uint16_t* out, int n, int dim, float t, hipStream_t
 // Q [n * Tq, ldq], K / V [n * Tk, ldk / ldv], O [n * Tq, ldo] bf16; head h = columns [h * dh, (h + 1) * dh); dh % 8 == 0, <= 160
 hipError_t sd_flash_attention(const uint16_t* Q, int64_t ldq, const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv,
                               uint16_t* O, int64_t ldo, int n, int heads, int Tq, int Tk, int dh, hipStream_t st);
+hipError_t sd_resize_norm(const float* in, float* out, int n, int H, int W, int Hr, int Wr, int oy, int ox, int S, int cubic,
+                          const float* mean, const float* sd, hipStream_t st);

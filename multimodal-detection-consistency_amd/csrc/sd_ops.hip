@@ -349,6 +349,60 @@ __global__ __launch_bounds__(256) void timestep_embed_kernel(uint16_t* __restric
     }
 }
 
+// ---- antialiased resize + centre crop + mean / std normalisation of fp32 NCHW images (values in [0, 1]): the CLIP
+// `preprocess` (bicubic, a = -0.5) or the reference's torchvision Resize (bilinear) applied to generated references
+// without leaving the GPU.  PIL / torch(antialias=True) semantics: the filter support is scaled by the downscale factor,
+// weights are normalised per output pixel, separable.  One thread per output element; the two 1-D weight sets
+// are recomputed per thread (support <= 2 * 2 * scale + 2 taps: a few dozen).
+template <int CUBIC>
+__device__ __forceinline__ float resize_filter(float x) {
+    x = fabsf(x);
+    if (CUBIC) {
+        const float a = -0.5f;
+        if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+        if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+        return 0.f;
+    }
+    return x < 1.f ? 1.f - x : 0.f;
+}
+
+template <int CUBIC>
+__global__ __launch_bounds__(256) void resize_norm_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int H, int W,
+                                                          int Hr, int Wr, int oy, int ox, int S, float m0, float m1, float m2,
+                                                          float s0, float s1, float s2) {
+    const int64_t total = (int64_t)n * 3 * S * S;
+    const float sy = (float)H / (float)Hr, sx = (float)W / (float)Wr;
+    const float fy = sy > 1.f ? sy : 1.f, fx = sx > 1.f ? sx : 1.f;          // filter scale (antialias only when shrinking)
+    const float supy = (CUBIC ? 2.f : 1.f) * fy, supx = (CUBIC ? 2.f : 1.f) * fx;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int x = (int)(t % S);
+        int64_t r = t / S;
+        const int y = (int)(r % S);
+        r /= S;
+        const int c = (int)(r % 3);
+        const int64_t img = r / 3;
+        const float cy = ((float)(y + oy) + 0.5f) * sy, cx = ((float)(x + ox) + 0.5f) * sx;
+        int y0 = (int)(cy - supy + 0.5f), y1 = (int)(cy + supy + 0.5f);
+        int x0 = (int)(cx - supx + 0.5f), x1 = (int)(cx + supx + 0.5f);
+        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+        y1 = y1 > H ? H : y1; x1 = x1 > W ? W : x1;
+        float wys = 0.f, wxs = 0.f;
+        for (int yy = y0; yy < y1; ++yy) wys += resize_filter<CUBIC>(((float)yy + 0.5f - cy) / fy);
+        for (int xx = x0; xx < x1; ++xx) wxs += resize_filter<CUBIC>(((float)xx + 0.5f - cx) / fx);
+        const float* p = in + (img * 3 + c) * (int64_t)H * W;
+        float acc = 0.f;
+        for (int yy = y0; yy < y1; ++yy) {
+            const float wy = resize_filter<CUBIC>(((float)yy + 0.5f - cy) / fy);
+            float row = 0.f;
+            for (int xx = x0; xx < x1; ++xx) row += resize_filter<CUBIC>(((float)xx + 0.5f - cx) / fx) * p[(int64_t)yy * W + xx];
+            acc += wy * row;
+        }
+        acc /= (wys * wxs);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        out[t] = (acc - mean) / sd;
+    }
+}
+
 inline int grid_for(int64_t total) {
     const int64_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -468,5 +522,20 @@ hipError_t sd_tokens_bf16_to_nchw(const uint16_t* in, float* out, int n, int C, 
 
 hipError_t sd_timestep_embed(uint16_t* out, int n, int dim, float t, hipStream_t st) {
     hipLaunchKernelGGL(timestep_embed_kernel, dim3(grid_for((int64_t)n * dim)), dim3(256), 0, st, out, n, dim, t);
+    return hipGetLastError();
+}
+
+// in fp32 [n, 3, H, W] -> out fp32 [n, 3, S, S]: resize to (Hr, Wr), crop at (oy, ox), (v - mean) / std; cubic: bicubic else bilinear
+hipError_t sd_resize_norm(const float* in, float* out, int n, int H, int W, int Hr, int Wr, int oy, int ox, int S, int cubic,
+                          const float* mean, const float* sd, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (H < 1 || W < 1 || Hr < S || Wr < S || oy < 0 || ox < 0 || oy + S > Hr || ox + S > Wr) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)n * 3 * S * S;
+    if (cubic)
+        hipLaunchKernelGGL(resize_norm_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, in, out, n, H, W, Hr, Wr, oy, ox, S, mean[0],
+                           mean[1], mean[2], sd[0], sd[1], sd[2]);
+    else
+        hipLaunchKernelGGL(resize_norm_kernel<0>, dim3(grid_for(total)), dim3(256), 0, st, in, out, n, H, W, Hr, Wr, oy, ox, S, mean[0],
+                           mean[1], mean[2], sd[0], sd[1], sd[2]);
     return hipGetLastError();
 }

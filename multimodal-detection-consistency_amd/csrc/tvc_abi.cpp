@@ -747,6 +747,15 @@ int tvc_pgd_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const fl
     return TVC_OK;
 }
 
+int tvc_l2_step(tvc_handle* h, float* adv_dev, const float* clean_dev, const float* grad_dev, int32_t B, int64_t n, float eps,
+                float step, float clip_min, float clip_max, int32_t descent, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (B < 0 || n < 0 || (B > 0 && n > 0 && (!adv_dev || !clean_dev || !grad_dev)))
+        return fail(h, TVC_E_INVALID, "tvc_l2_step: bad arguments");
+    HIP_TRY(launch_l2_step(adv_dev, clean_dev, grad_dev, B, n, eps, step, clip_min, clip_max, descent, (hipStream_t)stream));
+    return TVC_OK;
+}
+
 int tvc_attention_backward(tvc_handle* h, const uint16_t* qkv_dev, const uint16_t* dout_dev, uint16_t* dqkv_dev, int32_t n_seq,
                            int32_t seq_len, int32_t heads, void* stream) {
     if (!h) return TVC_E_INVALID;

@@ -628,6 +628,21 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
     });
 }
 
+int tvc_preprocess_images(tvc_handle* h, const float* images_dev, int32_t n, int32_t H, int32_t W, int32_t S, int32_t filter,
+                          int32_t keep_aspect, const float* mean3, const float* std3, float* out_dev, void* stream) {
+    if (!h) return TVC_E_INVALID;
+    if (n < 0 || H < 1 || W < 1 || S < 1 || !mean3 || !std3 || (n > 0 && (!images_dev || !out_dev)) || filter < 0 || filter > 1)
+        return fail(h, TVC_E_INVALID, "tvc_preprocess_images: bad arguments");
+    int Hr = S, Wr = S;
+    if (keep_aspect) {               // short side -> S (rounded as PIL does), centre crop
+        if (H <= W) Wr = (int)((double)W * S / H + 0.5); else Hr = (int)((double)H * S / W + 0.5);
+        if (Hr < S) Hr = S;
+        if (Wr < S) Wr = S;
+    }
+    HIP_TRY(sd_resize_norm(images_dev, out_dev, n, H, W, Hr, Wr, (Hr - S) / 2, (Wr - S) / 2, S, filter, mean3, std3, (hipStream_t)stream));
+    return TVC_OK;
+}
+
 int tvc_sd_attention(tvc_handle* h, const uint16_t* q_dev, const uint16_t* k_dev, const uint16_t* v_dev, uint16_t* out_dev, int32_t n,
                      int32_t heads, int32_t Tq, int32_t Tk, int32_t dh, void* stream) {
     if (!h) return TVC_E_INVALID;

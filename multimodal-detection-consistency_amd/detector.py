@@ -193,24 +193,34 @@ class AdversarialDetector:
                     keep_features["text"] = torch.empty((n, ft.shape[-1]), dtype=ft.dtype, device=ft.device)
                     keep_features["image"] = fi
                 keep_features["text"][torch.as_tensor(ids, device=ft.device)] = ft[:, 0]
-        # SD-reference method: arithmetic in scope (src/detector.py:528-553), producing the reference
-        # images is not -- they come from the caller or an injected generator.  ONE encode of all
+        # SD-reference method (src/detector.py:503-557): references from the caller, or from the generator
+        # (sd_ref.SDReferenceGenerator over sd_model.StableDiffusionModel: tvc_sd_generate).  ONE encode of all
         # reference images, one consistency launch per distinct count (cos(image, ref_j) = record words 0, 12..).
         sd_pending, sd_counts = [], [0] * n
         if sd_on:
-            per_q = []
-            for i in range(n):
-                if reference_images is not None:
-                    refs = reference_images[i]
-                else:
-                    refs = self.sd_generator.generate_reference_images(
-                        texts[i], num_images=self.config.num_reference_images).get("images", [])
-                per_q.append(list(refs) if refs is not None else [])
-            sd_counts = [len(r) for r in per_q]
-            all_refs = [im for r in per_q for im in r]
-            if all_refs:
-                xr, _ = clip._images_to_device(all_refs)
-                fr = eng.encode_image(xr, True)
+            fr = None
+            if reference_images is None and hasattr(self.sd_generator, "reference_features"):
+                # a generator of this package: every prompt x seed of the batch in the SAME UNet launches, references
+                # preprocessed on the device and encoded in one image-tower launch (sd_ref.SDReferenceGenerator)
+                if getattr(self.sd_generator, "clip_model", None) is None:
+                    self.sd_generator.clip_model = clip
+                fr, sd_counts = self.sd_generator.reference_features(list(texts), self.config.num_reference_images)
+                sd_counts = list(sd_counts)
+            else:
+                per_q = []
+                for i in range(n):
+                    if reference_images is not None:
+                        refs = reference_images[i]
+                    else:
+                        refs = self.sd_generator.generate_reference_images(
+                            texts[i], num_images=self.config.num_reference_images).get("images", [])
+                    per_q.append(list(refs) if refs is not None else [])
+                sd_counts = [len(r) for r in per_q]
+                all_refs = [im for r in per_q for im in r]
+                if all_refs:
+                    xr, _ = clip._images_to_device(all_refs)
+                    fr = eng.encode_image(xr, True)
+            if fr is not None and fr.shape[0]:
                 offs = np.concatenate([[0], np.cumsum(sd_counts)])
                 by_count: Dict[int, List[int]] = {}
                 for i, c in enumerate(sd_counts):
@@ -436,10 +446,17 @@ class MultiModalDefenseDetector:
         self.config = config or DetectionConfig()
         self.text_variant_generator = text_generator if text_generator is not None else qwen_model
         self.retrieval_generator = retrieval_generator
-        # object with generate_references(text) -> list of image tensors (experiments/defenses/generative_ref.py:71);
-        # the diffusion model behind it is not part of this build -- injected or absent
-        self.generative_generator = generative_generator if generative_generator is not None else (
-            sd_model if hasattr(sd_model, "generate_references") else None)
+        # object with generate_references(text) -> list of image tensors (experiments/defenses/generative_ref.py:71).
+        # A diffusion model (sd_model.StableDiffusionModel, or anything with the reference's `generate`) is wrapped
+        # in the GenerativeReferenceGenerator mirror, as experiments/defenses/detector.py:99-105 does.
+        if generative_generator is None and sd_model is not None:
+            if hasattr(sd_model, "generate_references"):
+                generative_generator = sd_model
+            elif hasattr(sd_model, "generate_batch") or hasattr(sd_model, "generate"):
+                from .sd_ref import GenerativeConfig, GenerativeReferenceGenerator
+                generative_generator = GenerativeReferenceGenerator(
+                    sd_model, clip_model, GenerativeConfig(generation_count=self.config.generation_count))
+        self.generative_generator = generative_generator
         # this detector's own bank slot on the (shared) engine; an injected RetrievalReferenceGenerator
         # brings its registered features.npy rows with it
         self.bank_name = getattr(retrieval_generator, "bank_name", None) or f"defense:{id(self):x}"

@@ -260,6 +260,18 @@ class TVCEngine:
                                               adv.numel() // max(B, 1), eps, alpha, mu, clip_min, clip_max,
                                               int(targeted), _stream()))
 
+    def l2_step(self, adv: torch.Tensor, clean: torch.Tensor, grad: torch.Tensor, eps: float, step: float,
+                clip_min: float = 0.0, clip_max: float = 1.0, descent: bool = True) -> None:
+        """One L2-normalised gradient step + projection onto the eps L2 ball + clamp, in place on ``adv``
+        (src/attacks/hubness_attack.py:378-386)."""
+        for name, t in (("adv", adv), ("clean", clean), ("grad", grad)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == adv.shape):
+                raise ValueError(f"{name}: contiguous fp32 device tensor shaped like adv expected")
+        B = adv.shape[0]
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_l2_step(self.handle, _ptr(adv), _ptr(clean), _ptr(grad), B, adv.numel() // max(B, 1),
+                                             eps, step, clip_min, clip_max, int(descent), _stream()))
+
     def encode_text(self, tokens: torch.Tensor, normalize: bool = True, group: int = 0) -> torch.Tensor:
         """tokens int [T, ctx] (on the GPU) -> fp32 [T, D].  ``group`` = N + 1 declares that the rows
         are consecutive (original, variant_1 .. variant_N) groups: variants then share the rows of
@@ -513,6 +525,19 @@ class TVCEngine:
             self._check(self.lib.tvc_layernorm_backward(self.handle, _ptr(x), _ptr(dy), _ptr(g), _ptr(dres), _ptr(dx),
                                                         x.shape[0], x.shape[1], _stream()))
         return dx
+
+    def preprocess_images(self, images: torch.Tensor, size: int, mean, std, bicubic: bool = True,
+                          keep_aspect: bool = True) -> torch.Tensor:
+        """images fp32 [n, 3, H, W] in [0, 1] (on the GPU) -> fp32 [n, 3, size, size]: antialiased resize (+ centre crop)
+        and (x - mean) / std in one kernel (``tvc_preprocess_images``)."""
+        images = _require_cuda(images, torch.float32, "images")
+        n, _, H, W = images.shape
+        out = torch.empty((n, 3, size, size), dtype=torch.float32, device=self.device)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_preprocess_images(self.handle, _ptr(images), n, H, W, size, int(bicubic), int(keep_aspect),
+                                                       m3, s3, _ptr(out), _stream()))
+        return out
 
     def gemm_f32(self, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -6,12 +6,16 @@ Mirror of ``src/sd_ref.py``: ``QualityMetrics`` (:24-46), ``GenerationResult`` (
 and -- new -- ``reference_features``: the CLIP image embeddings of everything generated, encoded in ONE batched
 ``tvc_encode_image`` launch (what K6 of the detector consumes; ``src/detector.py:524-548``).
 
-What is NOT built: the latent-diffusion model itself (UNet + VAE + scheduler).  The reference reaches it through
-``StableDiffusionModel.generate_image(prompt=, num_images=, seed=, num_inference_steps=, guidance_scale=, height=,
-width=)`` (:389-399), a wrapper that is absent from the reference snapshot too, like its weights; here it is an
-injected object with that method (``sd_model=``), as the language model is for the text variants.  Its text
-conditioning, the CLIP text tower's per-token output, IS available on the GPU: ``TVCEngine.encode_text_hidden``
-(``tvc_encode_text_hidden``).
+The latent-diffusion model itself (UNet + VAE decoder + PNDM scheduler) is ``sd_model.StableDiffusionModel`` on the HIP
+kernels of ``tvc_sd_*``: the reference reaches it through ``StableDiffusionModel.generate_image(prompt=, num_images=,
+seed=, num_inference_steps=, guidance_scale=, height=, width=)`` (:389-399).  ``sd_model=None`` builds that model
+(``sd_model="none"`` keeps the generator without one, as the reference does when the pipeline fails to load); any
+object with ``generate_image`` can be injected instead.  ``reference_features`` is the batched form: every prompt x
+seed of a batch is denoised in the SAME UNet launches (``generate_batch``), preprocessed on the device
+(``tvc_preprocess_images``) and encoded in one image-tower launch -- no PIL round trip.
+
+``GenerativeReferenceGenerator`` mirrors ``experiments/defenses/generative_ref.py`` (:31-330): prompt preprocessing,
+``generate_references`` -> image tensors resized to 224 and ImageNet-normalised, consistency / quality metrics.
 """
 from __future__ import annotations
 
@@ -156,6 +160,12 @@ class SDReferenceGenerator:
 
     def __init__(self, config: Optional[SDReferenceConfig] = None, sd_model=None, text_augmenter=None, clip_model=None):
         self.config = config or SDReferenceConfig()
+        if sd_model is None:
+            from .sd_model import SDModelConfig, StableDiffusionModel
+            sd_model = StableDiffusionModel(SDModelConfig(model_name=self.config.sd_model, device=self.config.device),
+                                            clip_model=clip_model)
+        elif isinstance(sd_model, str) and sd_model == "none":
+            sd_model = None
         self.sd_model = sd_model
         self.text_augmenter = text_augmenter if self.config.use_text_variants else None
         self.clip_model = clip_model
@@ -169,7 +179,7 @@ class SDReferenceGenerator:
         c = self.config
         try:
             if self.sd_model is None:
-                raise RuntimeError("no sd_model injected (the latent-diffusion model is not part of this build)")
+                raise RuntimeError("this generator was built without a latent-diffusion model (sd_model='none')")
             num_images = num_images or c.num_images_per_prompt
             use_variants = use_variants if use_variants is not None else c.use_text_variants
             key = self._get_cache_key(prompt, num_images, use_variants, seeds)
@@ -222,6 +232,19 @@ class SDReferenceGenerator:
         ``encode_image(sd_references)`` of ``src/detector.py:527-533``."""
         if self.clip_model is None:
             raise ValueError("reference_features needs a clip_model")
+        if hasattr(self.sd_model, "generate_batch") and not self.config.filter_low_quality and \
+                not (self.config.use_text_variants and self.text_augmenter is not None):
+            # the batched path: all prompts x seeds in the same UNet launches, pixels stay on the device
+            c = self.config
+            num = num_images or c.num_images_per_prompt
+            flat_p = [p for p in prompts for _ in range(num)]
+            flat_s = [s for _ in prompts for s in self._generate_seeds(num)]
+            t0 = time.time()
+            imgs = self.sd_model.generate_batch(flat_p, flat_s, c.num_inference_steps, c.guidance_scale, c.height, c.width)
+            feats = self.clip_model.engine.encode_image(self.clip_model.preprocess_tensor(imgs), True)
+            self.generation_stats["total_generated"] += len(flat_p)
+            self.generation_stats["generation_time"] += time.time() - t0
+            return feats, [num] * len(prompts)
         results = self.batch_generate_reference_images(list(prompts), num_images)
         imgs = [im for r in results for im in r["images"]]
         counts = [len(r["images"]) for r in results]
@@ -299,3 +322,133 @@ class SDReferenceGenerator:
 
 def create_sd_reference_generator(config: Optional[SDReferenceConfig] = None, **kw) -> SDReferenceGenerator:
     return SDReferenceGenerator(config or SDReferenceConfig(), **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class GenerativeConfig:
+    """``experiments/defenses/generative_ref.py:17-28`` (same names and defaults)."""
+    generation_count: int = 3
+    image_size: int = 512
+    guidance_scale: float = 7.5
+    num_inference_steps: int = 20
+    seed: Optional[int] = None
+    negative_prompt: str = "blurry, low quality, distorted, deformed"
+    use_safety_checker: bool = True
+    batch_size: int = 1
+    device: str = "cuda"
+
+
+class GenerativeReferenceGenerator:
+    """Mirror of ``experiments/defenses/generative_ref.py:31-330``: ``generate_references(text)`` -> list of image
+    tensors [3, 224, 224] (resized to 224 x 224 bilinear, ImageNet mean / std, :55-59), ``batch_generate_references``,
+    ``compute_generation_consistency``, ``evaluate_generation_quality``, statistics.  ``sd_model`` = anything with the
+    reference's ``generate(prompt=, negative_prompt=, height=, width=, guidance_scale=, num_inference_steps=, generator=)``;
+    a ``StableDiffusionModel`` is driven through its batched form instead (all ``generation_count`` images of a text
+    share the UNet launches, resize + normalise on the device)."""
+
+    IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    QUALITY_WORDS = ("high quality", "detailed", "realistic", "professional photography")
+
+    def __init__(self, sd_model, clip_model, config: Optional[GenerativeConfig] = None):
+        self.sd_model, self.clip_model = sd_model, clip_model
+        self.config = config or GenerativeConfig()
+        self.generation_stats = {"total_generations": 0, "successful_generations": 0, "failed_generations": 0,
+                                 "average_generation_time": 0.0}
+
+    def _preprocess_text(self, text: str) -> str:
+        """:160-184."""
+        t = text.strip()
+        if not any(w in t.lower() for w in self.QUALITY_WORDS):
+            t = f"{t}, high quality, detailed"
+        if len(t) > 200:
+            t = t[:200].rsplit(" ", 1)[0]
+        return t
+
+    def _to_clip_tensor(self, images01: torch.Tensor) -> torch.Tensor:
+        return self.clip_model.engine.preprocess_images(images01, 224, self.IMAGENET_MEAN, self.IMAGENET_STD, bicubic=False,
+                                                        keep_aspect=False)
+
+    def generate_references(self, text: str) -> List[torch.Tensor]:
+        c = self.config
+        t0 = time.time()
+        out: List[torch.Tensor] = []
+        try:
+            prompt = self._preprocess_text(text)
+            if hasattr(self.sd_model, "generate_batch"):
+                seeds = [(c.seed + i) if c.seed is not None else random.randint(0, 2 ** 31 - 1) for i in range(c.generation_count)]
+                imgs = self.sd_model.generate_batch([prompt] * c.generation_count, seeds, c.num_inference_steps, c.guidance_scale,
+                                                    c.image_size, c.image_size, [c.negative_prompt] * c.generation_count)
+                out = list(self._to_clip_tensor(imgs))
+                self.generation_stats["successful_generations"] += len(out)
+            else:
+                for i in range(c.generation_count):
+                    try:
+                        gen = torch.Generator().manual_seed(c.seed + i) if c.seed is not None else None
+                        res = self.sd_model.generate(prompt=prompt, negative_prompt=c.negative_prompt, height=c.image_size,
+                                                     width=c.image_size, guidance_scale=c.guidance_scale,
+                                                     num_inference_steps=c.num_inference_steps, generator=gen)
+                        img = res.images[0] if hasattr(res, "images") and res.images else (res[0] if isinstance(res, list) and res else res)
+                        if img is None:
+                            self.generation_stats["failed_generations"] += 1
+                            continue
+                        a = torch.from_numpy(np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0).permute(2, 0, 1)[None]
+                        out.append(self._to_clip_tensor(a.to(self.clip_model.device))[0])
+                        self.generation_stats["successful_generations"] += 1
+                    except Exception as e:                     # noqa: BLE001 -- :118-121
+                        logger.warning("generation %d failed: %s", i + 1, e)
+                        self.generation_stats["failed_generations"] += 1
+            self.generation_stats["total_generations"] += c.generation_count
+            n = self.generation_stats["total_generations"]
+            avg = self.generation_stats["average_generation_time"]
+            self.generation_stats["average_generation_time"] = (avg * (n - c.generation_count) + (time.time() - t0)) / n
+        except Exception as e:                                 # noqa: BLE001 -- :132-134
+            logger.error("reference generation failed: %s", e)
+            out = []
+        return out
+
+    def batch_generate_references(self, texts: List[str]) -> List[List[torch.Tensor]]:
+        return [self.generate_references(t) for t in texts]
+
+    def compute_generation_consistency(self, text: str, generated_images: List[torch.Tensor]) -> Dict[str, float]:
+        """:224-275 with ONE image-tower launch and one cosine matrix instead of a launch per image / pair."""
+        if not generated_images:
+            return {"text_image_consistency": 0.0, "inter_image_consistency": 0.0}
+        tf = self.clip_model.encode_tokens(self.clip_model.tokenize([text]), True)
+        fi = self.clip_model.engine.encode_image(torch.stack(list(generated_images)).to(self.clip_model.device), True)
+        ti = (fi @ tf[0]).cpu().numpy().astype(np.float64)
+        g = (fi @ fi.t()).cpu().numpy().astype(np.float64)
+        iu = np.triu_indices(len(generated_images), 1)
+        return {"text_image_consistency": float(ti.mean()),
+                "inter_image_consistency": float(g[iu].mean()) if len(iu[0]) else 1.0,
+                "text_image_std": float(ti.std()), "generation_count": len(generated_images)}
+
+    def evaluate_generation_quality(self, text: str, generated_images: List[torch.Tensor],
+                                    reference_image: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """:277-330."""
+        if not generated_images:
+            return {"message": "no generated images to evaluate"}
+        ev: Dict[str, Any] = {"generation_count": len(generated_images),
+                              "consistency_metrics": self.compute_generation_consistency(text, generated_images)}
+        fi = self.clip_model.engine.encode_image(torch.stack(list(generated_images)).to(self.clip_model.device), True)
+        if reference_image is not None:
+            fr = self.clip_model.engine.encode_image(reference_image.unsqueeze(0).to(self.clip_model.device), True)
+            s = (fi @ fr[0]).cpu().numpy().astype(np.float64)
+            ev["reference_similarity"] = {"mean": float(s.mean()), "std": float(s.std()), "max": float(s.max()), "min": float(s.min())}
+        if len(generated_images) >= 2:
+            g = (fi @ fi.t()).cpu().numpy().astype(np.float64)
+            iu = np.triu_indices(len(generated_images), 1)
+            ev["diversity_score"] = float(np.clip(1.0 - g[iu].mean(), 0.0, 1.0))                      # :321-346
+        else:
+            ev["diversity_score"] = 0.0
+        cm = ev["consistency_metrics"]
+        inter = 1.0 - abs(cm.get("inter_image_consistency", 0.0) - 0.7)                                # :348-369, ideal value 0.7
+        ev["overall_quality"] = float(np.clip(0.5 * cm.get("text_image_consistency", 0.0) + 0.3 * inter +
+                                              0.2 * ev["diversity_score"], 0.0, 1.0))
+        return ev
+
+    def get_statistics(self) -> Dict[str, Any]:
+        s = dict(self.generation_stats)
+        tot = s["successful_generations"] + s["failed_generations"]
+        s["success_rate"] = s["successful_generations"] / tot if tot else 0.0
+        return s

@@ -6,10 +6,12 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/multimodal-detection-consistency_amd/csrc
 out=$root/gpurun_abl; mkdir -p $out/obj_$name
-for f in gemm gemm_solo elementwise attention bank consistency backward attention_bwd; do
+for f in gemm elementwise attention bank consistency backward attention_bwd precise sd_ops sd_attention; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
 done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip "$@" -c $src/tvc_abi.cpp -o $out/obj_$name/tvc_abi.o &
+for f in tvc_abi tvc_precise tvc_sd; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip "$@" -c $src/$f.cpp -o $out/obj_$name/$f.o &
+done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libtvc_$name.so $out/obj_$name/*.o
 echo built $out/libtvc_$name.so

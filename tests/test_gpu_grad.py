@@ -258,3 +258,40 @@ def test_hubness_attack_vs_autograd_recipe(pkg):
     assert atk.get_attack_stats()["total_attacks"] == 2 + B
     assert pkg.HubnessAttackPresets.weak_attack().num_iterations == 100
     clip.engine.close()
+
+
+def test_l2_step_and_hubness_l2_constraint(pkg):
+    """``norm_constraint='l2'`` (src/attacks/hubness_attack.py:378-386): the fused step kernel vs the reference's
+    formulas in torch, then the Hubness loop under the L2 constraint (perturbation inside the eps L2 ball, loss down)."""
+    arch = pkg.get_arch("ViT-T/16-test")
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    clip = pkg.CLIPModel(pkg.CLIPConfig(model_name=arch.name), weights=(vw, tw))
+    eng = clip.engine
+    g = torch.Generator().manual_seed(3)
+    B = 4
+    clean = torch.rand((B, 3, 64, 64), generator=g)
+    adv = torch.clamp(clean + 0.05 * torch.randn(clean.shape, generator=g), 0, 1)
+    grad = torch.randn(clean.shape, generator=g) * 1e-3
+    eps, step = 1.5, 0.3
+    for descent in (True, False):
+        a = adv.clone().cuda()
+        eng.l2_step(a, clean.cuda(), grad.cuda(), eps, step, 0.0, 1.0, descent)
+        gn = grad.view(B, -1).norm(dim=1, keepdim=True)
+        ref = adv + (-1 if descent else 1) * step * grad / (gn.view(-1, 1, 1, 1) + 1e-8)
+        d = ref - clean
+        dn = d.view(B, -1).norm(dim=1, keepdim=True)
+        d = d / (dn.view(-1, 1, 1, 1) + 1e-8) * torch.clamp(dn, max=eps).view(-1, 1, 1, 1)
+        ref = torch.clamp(clean + d, 0, 1)
+        assert (a.cpu() - ref).abs().max().item() < 2e-6
+    cfg = pkg.HubnessAttackConfig(clip_model=arch.name, num_iterations=8, epsilon=2.0, step_size=0.5, random_seed=5,
+                                  norm_constraint="l2", random_start=False)
+    atk = pkg.HubnessAttack(cfg, clip_model=clip)
+    imgs = torch.rand((2, 3, arch.image_size, arch.image_size), generator=g).cuda()
+    q_mean = atk._unit_queries(["a photo of a cat", "a dog playing"]).mean(0, keepdim=True).expand(2, -1).contiguous()
+    f0 = eng.encode_image(imgs, True)
+    best, best_loss = atk._optimise(imgs, q_mean)
+    assert ((best - imgs).flatten(1).norm(dim=1) <= cfg.epsilon + 1e-4).all()
+    assert (best_loss < -(f0 * q_mean).sum(-1) + 1e-6).all()
+    with pytest.raises(ValueError):
+        pkg.HubnessAttack(pkg.HubnessAttackConfig(clip_model=arch.name, norm_constraint="l1"), clip_model=clip)
+    eng.close()

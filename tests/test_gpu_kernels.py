@@ -167,13 +167,13 @@ def test_cosine_matrix(gpu_engine, pkg, N, M, D):
     assert (out.double().cpu() - ref).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("env", [{"TVC_GEMM_VARIANT": "2"}, {"TVC_GEMM_SPLITK_TAIL": "1"}, {"TVC_GEMM_SPLITK_SMALL": "1"},
-                                 {"TVC_GEMM_RING_FORM": "1"}, {"TVC_GEMM_RING_FORM": "2"}, {"TVC_GEMM_RING_FORM": "3"}])
+@pytest.mark.parametrize("env", [{"TVC_GEMM_SPLITK_TAIL": "1"}, {"TVC_GEMM_SPLITK_SMALL": "1"}, {"TVC_GEMM_RING_FORM": "1"},
+                                 {"TVC_GEMM_VARIANT": "0"}])
 def test_gemm_variants_in_subprocess(env):
-    """Env switches read once per process: TVC_GEMM_VARIANT=2 selects gemm_solo_kernel for the
-    ring-eligible bf16 GEMMs (incl. a ragged token remainder), TVC_GEMM_SPLITK_TAIL=1 the split-K tail
-    for left-over tile columns, TVC_GEMM_SPLITK_SMALL=1 split-K for GEMMs of a few tiles (latency mode).
-    Same outputs as the PyTorch restatement."""
+    """Env switches read once per process: TVC_GEMM_SPLITK_TAIL=1 the split-K tail for left-over tile columns,
+    TVC_GEMM_SPLITK_SMALL=1 split-K for GEMMs of a few tiles (latency mode), TVC_GEMM_RING_FORM=1 the general ring
+    form everywhere, TVC_GEMM_VARIANT=0 the one-tile-per-workgroup kernel everywhere.  Same outputs as the PyTorch
+    restatement.  (Ring forms 2 / 3 and the four-wave kernel were removed in round 3.)"""
     import os
     import subprocess
     import sys
@@ -203,7 +203,7 @@ print("SOLO_OK")
 
 def test_ring_forms_are_bit_identical():
     """every ring form sums each output element over K in the same order and runs the same epilogue
-    arithmetic, so forms 1, 3 and 4 (the default) return the same BITS on tower-sized launches (incl. QuickGELU, a
+    arithmetic, so forms 1 and 4 (the default) return the same BITS on tower-sized launches (incl. QuickGELU, a
     ragged number of tile rounds, K = 64 and the fp32 epilogue).  scripts/gemm_form_check.py prints a checksum of the
     raw output bits per shape; the env switch is read once per process, hence the subprocesses."""
     import os
@@ -211,14 +211,14 @@ def test_ring_forms_are_bit_identical():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = {}
-    for form in ("1", "3", "4"):
+    for form in ("1", "4"):
         env = dict(os.environ, TVC_GEMM_RING_FORM=form)
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gemm_form_check.py")], cwd=root, env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "FORM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         sums[form] = [ln.split("checksum")[1].strip() for ln in r.stdout.splitlines() if "checksum" in ln]
         assert len(sums[form]) == 8
-    assert sums["1"] == sums["3"] == sums["4"], sums
+    assert sums["1"] == sums["4"], sums
 
 
 def test_bank_filter_ring_and_one_tile_loops_agree():

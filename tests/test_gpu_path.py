@@ -321,11 +321,20 @@ def test_two_shard_search_equals_full_search(gpu_engine):
             assert (mm[:, 3].cpu() - (S >= 0.05).sum(1).cpu()).abs().max() <= 1
 
 
-def test_sharded_search_two_phase_on_gpu(gpu_engine, pkg, tmp_path):
-    """``ShardedBankSearch`` with the product ops (``HipShardOps``) in a one-rank process group: the
-    two-phase exchange (merge of index / similarity lists, then only the winners' rows) returns what a
-    direct search + gather returns, bit for bit; so does the single-phase form."""
+def _nccl_group(tmp_path, name):
+    """A ONE-rank RCCL process group on cuda:0 (fresh per test): all_gather_into_tensor and all_to_all_single --
+    equal and split sizes -- then execute on the GPU box exactly as they do on an 8-GPU node."""
     import torch.distributed as dist
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/{name}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    return dist
+
+
+def test_sharded_search_on_gpu_over_rccl(gpu_engine, pkg, tmp_path):
+    """``ShardedBankSearch`` with the product ops (``HipShardOps``) in a one-rank **nccl (RCCL)** process group: the
+    fused single-collective exchange (default, no host synchronisation), the two-phase exchange (variable-size
+    all_to_all_single with split sizes) and the single-phase form all return what a direct search + gather returns,
+    bit for bit; ``feat_from`` skips the leading rows."""
     R, D, M, k, kf = 30011, 256, 130, 8, 5
     bank = _unit((R, D), 41).to(torch.bfloat16).cuda()
     q = _unit((M, D), 42).cuda()
@@ -333,12 +342,19 @@ def test_sharded_search_two_phase_on_gpu(gpu_engine, pkg, tmp_path):
     ri, rs, _ = gpu_engine.bank_search(q, k, 0.3, want_moments=False)
     rf = gpu_engine.bank_gather(ri[:, :kf].contiguous())
     gpu_engine.bank_status()
-    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    dist = _nccl_group(tmp_path, "pg")
     try:
-        for per in (None, R):
-            s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=per)
+        assert dist.get_backend() == "nccl"
+        for mode, per in (("fused", None), ("fused", R), ("two_phase", R), ("single_phase", None)):
+            s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=per, mode=mode)
             i, v, f = s.search(q, k, kf)
-            assert torch.equal(i, ri) and torch.equal(v, rs) and torch.equal(f, rf)
+            assert torch.equal(i, ri) and torch.equal(v, rs) and torch.equal(f, rf), mode
+            if mode == "fused":
+                assert s.last_exchange["host_syncs"] == 0
+                s.check_status()
+                i2, v2, f2 = s.search(q, k, kf, feat_from=30)
+                assert torch.equal(i2, ri) and torch.equal(v2, rs) and torch.equal(f2[30:], rf[30:])
+                assert float(f2[:30].abs().max()) == 0.0
     finally:
         dist.destroy_process_group()
 
@@ -522,22 +538,30 @@ def test_text_hidden_states_vs_oracle(pkg):
 
 def test_sharded_search_with_a_degenerate_shard(gpu_engine, pkg, tmp_path):
     """Round-1 advice: a shard whose candidate lists overflow (40 000 identical rows) must not hand the merge a
-    silently truncated list.  ``HipShardOps.search`` goes through ``bank_search_robust``: the overflow is seen
-    (``dense_fallbacks`` counts it) and the shard's answer is the brute-force one -- exact."""
-    import torch.distributed as dist
+    silently truncated list.  Fused (asynchronous) form: ``check_status`` raises TVC_E_OVERFLOW on every rank;
+    status-checked forms: ``HipShardOps.search`` goes through ``bank_search_robust`` (``dense_fallbacks`` counts it)
+    and the shard's answer is the brute-force one -- exact.  One-rank RCCL group."""
     D, M, k, kf = 256, 40, 5, 5
     row = _unit((1, D), 5)
     bank = torch.cat([row.repeat(40000, 1), _unit((500, D), 6)]).to(torch.bfloat16).cuda()
     q = torch.cat([_unit((M - 1, D), 7), row]).cuda()
     gpu_engine.set_bank(bank)
     before = getattr(gpu_engine, "dense_fallbacks", 0)
-    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg2", rank=0, world_size=1)
+    dist = _nccl_group(tmp_path, "pg2")
     try:
-        s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=bank.shape[0])
+        fused = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3))
+        fused.search(q, k, kf)
+        try:
+            fused.check_status()
+            overflowed = False
+        except pkg.TVCError as e:
+            overflowed = e.code == pkg._lib.TVC_E_OVERFLOW
+        s = pkg.sharding.ShardedBankSearch(pkg.sharding.HipShardOps(gpu_engine, 0, 0.3), rows_per_shard=bank.shape[0], mode="two_phase")
         i, v, f = s.search(q, k, kf)
     finally:
         dist.destroy_process_group()
     assert getattr(gpu_engine, "dense_fallbacks", 0) > before, "the overflow must have been detected"
+    assert overflowed, "the asynchronous form must report the overflow through check_status"
     S = q.double() @ bank.double().t()
     want_v, _ = S.topk(k, dim=1)
     assert (v.double() - want_v).abs().max().item() < 1e-5

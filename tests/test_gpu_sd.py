@@ -160,3 +160,73 @@ def test_sampling_loop_vs_oracle(pkg, sd):
     # the scheduler arithmetic alone (same eps on both sides would be exact): timesteps visited
     sch = sd_oracle.PNDMOracle(arch)
     assert sch.set_timesteps(steps) == [801, 601, 601, 401, 201, 1]
+
+
+def test_preprocess_images_matches_torch_antialias(pkg, sd):
+    """``tvc_preprocess_images`` (resize + centre crop + normalise on the device) vs torch's antialiased interpolate on
+    the CPU (the PIL filter semantics on float pixels): bicubic short-side + crop (CLIP preprocess) and bilinear
+    both-sides (torchvision Resize((224, 224)) of experiments/defenses/generative_ref.py:55-59)."""
+    F = torch.nn.functional
+    eng = sd[3].engine
+    g = torch.Generator().manual_seed(8)
+    for (H, W) in ((512, 512), (300, 420), (224, 224), (150, 100)):
+        x = torch.rand((2, 3, H, W), generator=g)
+        mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+        got = eng.preprocess_images(x.cuda(), 224, mean, std, bicubic=True, keep_aspect=True).cpu()
+        s = 224 / min(H, W)
+        Hr, Wr = (224, max(224, int(W * 224 / H + 0.5))) if H <= W else (max(224, int(H * 224 / W + 0.5)), 224)
+        r = F.interpolate(x, size=(Hr, Wr), mode="bicubic", antialias=True, align_corners=False)
+        oy, ox = (Hr - 224) // 2, (Wr - 224) // 2
+        r = r[:, :, oy:oy + 224, ox:ox + 224]
+        ref = (r - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        assert (got - ref).abs().max().item() < 2e-4, (H, W, (got - ref).abs().max().item())
+        got2 = eng.preprocess_images(x.cuda(), 224, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), bicubic=False, keep_aspect=False).cpu()
+        r2 = F.interpolate(x, size=(224, 224), mode="bilinear", antialias=True, align_corners=False)
+        ref2 = (r2 - torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)) / torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+        assert (got2 - ref2).abs().max().item() < 2e-4, (H, W)
+
+
+def test_config4_smoke_sd_reference_generator_feeds_the_detector(pkg):
+    """BASELINE configs[4] in miniature: 2 prompts x 3 images x 4 PLMS steps at the full 64 x 64 latent / 512 x 512 pixel
+    geometry -> references -> CLIP embeddings -> the detector's sd_reference score (src/detector.py:503-557), checked
+    against the oracle's arithmetic on the SAME embeddings (1e-4); plus the defence detector's generative branch."""
+    from oracle import tvc_oracle
+    arch = pkg.get_arch("ViT-L/14")
+    clip = pkg.CLIPModel(pkg.CLIPConfig(model_name="ViT-L/14"), weights=pkg.synth.make_clip_weights(arch, seed=0))
+    gen = pkg.SDReferenceGenerator(pkg.SDReferenceConfig(num_images_per_prompt=3, num_inference_steps=4, use_text_variants=False,
+                                                         filter_low_quality=False, enable_cache=False), clip_model=clip)
+    assert isinstance(gen.sd_model, pkg.StableDiffusionModel) and gen.sd_model.text_engine is clip.engine
+    texts = ["a dog running on the beach", "two people riding bicycles in a city street"]
+    feats, counts = gen.reference_features(texts, 3)
+    assert counts == [3, 3] and feats.shape == (6, arch.embed_dim) and torch.isfinite(feats).all()
+    assert (feats.norm(dim=-1) - 1).abs().max().item() < 1e-4
+    # different prompts / seeds give different references; the same call again gives the same ones (seed policy)
+    assert (feats[0] - feats[1]).abs().max().item() > 1e-4 and (feats[0] - feats[3]).abs().max().item() > 1e-4
+    feats2, _ = gen.reference_features(texts, 3)
+    assert torch.equal(feats, feats2)
+    # ---- the detector consumes them: sd_reference = 1 - mean cos(image, ref_j) on the same embeddings
+    images = pkg.synth.make_images(2, arch.image_size, seed=3).cuda()
+    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model="ViT-L/14", num_reference_images=3, use_text_variants=False),
+                                  clip_model=clip, sd_generator=gen)
+    res = det.batch_detect(images, texts, methods=["sd_reference", "consistency"])
+    fi = clip.engine.encode_image(images).cpu().numpy().astype(np.float64)
+    fr = feats.cpu().numpy().astype(np.float64).reshape(2, 3, -1)
+    for i, r in enumerate(res):
+        want, _ = tvc_oracle.sd_reference_score(fr[i] @ fi[i])           # rows are unit vectors: cosines
+        got = r["detection_scores"]["sd_reference"]
+        assert abs(got - want) < 1e-4, (got, want)
+        assert r["detection_details"]["sd_reference"]["num_references"] == 3
+        agg = (0.4 * got + 0.2 * r["detection_scores"]["consistency"]) / 0.6
+        assert abs(r["aggregated_score"] - agg) < 1e-6
+    # ---- PIL-returning API of the reference (src/sd_ref.py:389-399) and the generative branch of the defence detector
+    pil = gen.sd_model.generate_image(prompt=texts[0], num_images=1, seed=0, num_inference_steps=2, height=512, width=512)
+    assert len(pil) == 1 and pil[0].size == (512, 512)
+    dd = pkg.MultiModalDefenseDetector(clip, sd_model=gen.sd_model,
+                                       config=pkg.DetectionConfig(use_text_variants=False, use_retrieval_ref=False,
+                                                                  generation_count=2, adaptive_threshold=False))
+    dd.generative_generator.config.num_inference_steps = 2
+    dd.generative_generator.config.seed = 5
+    out = dd.detect(images[:1], texts[0], return_details=True)
+    assert "generative_consistency" in out["details"]["consistency_scores"]
+    assert np.isfinite(out["consistency_score"])
+    clip.engine.close()

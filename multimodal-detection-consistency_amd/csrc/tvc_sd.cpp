@@ -106,7 +106,10 @@ struct Run {
         Act col = act(x.n, Ho, Wo, 9 * x.C);
         const void* w = W(prefix + "weight");
         const float* b = (const float*)W(prefix + "bias");
-        if (live()) hip(sd_im2col3x3(x.p, col.p, x.n, x.H, x.W, x.C, stride, up, st), "sd_im2col3x3");
+        if (live()) {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)col.tok() * 9 * x.C * 4.0);      // rows written once, read once by the GEMM
+            hip(sd_im2col3x3(x.p, col.p, x.n, x.H, x.W, x.C, stride, up, st), "sd_im2col3x3");
+        }
         gemm(w, Cout, 9 * x.C, col.p, col.tok(), b, y.p, Cout, TVC_EPI_BF16);
         off = mark;
         return y;

@@ -439,6 +439,8 @@ typedef struct { const char* name; const void* ptr; } tvc_named_tensor;
  *   attn1.to_q|to_k|to_v            -> one bf16 "....attn1.to_qkv.weight" [3C, C];  attn2.to_k|to_v -> "....attn2.to_kv.weight" [2C, 768]
  *   VAE query|key|value             -> "....to_qkv.weight" bf16 [3C, C] and "....to_qkv.bias" fp32 [3C]
  *   biases, norm gains / offsets, post_quant_conv.weight [4, 4]  -> fp32
+ *   every bf16 matrix must be READABLE up to the next multiple of 256 rows (zero rows appended by the host): the GEMM
+ *   stages whole 256-row tiles of it even where Co (320, 640, 4 ...) is not a multiple of 256
  * Referenced, not copied (the caller keeps them alive), except the resnets' time projections, which are gathered into
  * one matrix inside the handle.  Either half may be absent (UNet-only / VAE-only handles). */
 int tvc_sd_load(tvc_handle* h, const tvc_sd_desc* desc, const tvc_named_tensor* tensors, int32_t n_tensors, void* stream);

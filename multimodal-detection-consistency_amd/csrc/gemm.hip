@@ -518,7 +518,8 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     g.A = L.A; g.B = L.B; g.lda = L.lda; g.ldb = L.ldb; g.I = L.I; g.J = L.J;
     g.ksteps_per_plane = L.K / GEMM_BK;
     g.planes = L.planes;
-    for (int p = 0; p < 4; ++p) { g.a_plane_off[p] = L.a_plane_off[p]; g.b_plane_off[p] = L.b_plane_off[p]; }
+    if (L.planes < 1 || L.planes > GEMM_MAX_PLANES) return hipErrorInvalidValue;
+    for (int p = 0; p < GEMM_MAX_PLANES; ++p) { g.a_plane_off[p] = L.a_plane_off[p]; g.b_plane_off[p] = L.b_plane_off[p]; }
     GemmEpilogue e;
     e.bias = L.bias; e.out = L.out; e.ldo = L.ldo;
     const int nIt = (L.I + GEMM_BM - 1) / GEMM_BM, nJt = (L.J + GEMM_BN - 1) / GEMM_BN;
@@ -583,7 +584,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         // form 4 reads whole rows without clamping: out-feature rows must fill whole tiles, B must have readable
         // rows up to the next multiple of 256 (J % 256 == 0, or a padded workspace: GemmLaunch::b_rows_padded), and
         // the row pitches must be multiples of 128 bytes (its source swizzle flips address bit 6)
-        if (ring_form == 4 && L.epilogue != TVC_EPI_RESID_F32 && L.I % GEMM_BM == 0 &&
+        if (ring_form == 4 && L.epilogue != TVC_EPI_RESID_F32 && (L.I % GEMM_BM == 0 || L.a_rows_padded) &&
             (L.J % GEMM_BN == 0 || L.b_rows_padded) && L.lda % 64 == 0 && L.ldb % 64 == 0) {
             switch (L.epilogue) {
                 case TVC_EPI_F32:

@@ -27,6 +27,7 @@
 #define GEMM_BN 256          // J rows per workgroup
 #define GEMM_BK 64
 #define GEMM_THREADS 512
+#define GEMM_MAX_PLANES 9
 #define GEMM_TILE_BYTES (256 * 64 * 2)            // 32 KiB
 #define GEMM_LDS_BYTES (4 * GEMM_TILE_BYTES)      // 128 KiB
 
@@ -36,9 +37,9 @@ struct GemmOperands {
     int64_t lda, ldb;          // elements
     int I, J;                  // valid rows of A / B (loads clamp to the last row)
     int ksteps_per_plane;      // K / 64
-    int planes;                // 1..4
-    int a_plane_off[4];
-    int b_plane_off[4];
+    int planes;                // 1..GEMM_MAX_PLANES (2-3: split-bf16 operands; 9: the taps of a 3x3 convolution)
+    int a_plane_off[GEMM_MAX_PLANES];
+    int b_plane_off[GEMM_MAX_PLANES];
 };
 
 typedef f32x4_t gemm_acc_t[8][4];

@@ -12,8 +12,9 @@ struct GemmLaunch {
     int64_t lda = 0, ldb = 0;
     int I = 0, J = 0, K = 0;       // K per plane, multiple of 64
     int planes = 1;
-    int a_plane_off[4] = {0, 0, 0, 0};
-    int b_plane_off[4] = {0, 0, 0, 0};
+    int a_plane_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // up to GEMM_MAX_PLANES
+    int b_plane_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool a_rows_padded = false;    // A has readable rows up to the next multiple of 256 beyond I (form 4 with a ragged last row tile)
     const float* bias = nullptr;   // [I]
     void* out = nullptr;           // [J, ldo]
     int64_t ldo = 0;
@@ -152,13 +153,17 @@ hipError_t sd_im2col3x3(const uint16_t* in, uint16_t* out, int n, int Hi, int Wi
 hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, int W, int Kp, float scale, hipStream_t st);
 size_t sd_groupnorm_ws_floats(int n, int HW, int groups);
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
-                        int n, int HW, int C, int groups, float eps, int silu, float* ws, hipStream_t st);
+                        int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
+                        hipStream_t st);
+hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, hipStream_t st);
+hipError_t sd_add_padded(const uint16_t* a, const uint16_t* b_padded, uint16_t* out, int n, int H, int W, int C, hipStream_t st);
 hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps, hipStream_t st);
 hipError_t sd_geglu(const uint16_t* in, uint16_t* out, int64_t rows, int Ch, hipStream_t st);
 hipError_t sd_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, hipStream_t st);
 hipError_t sd_concat(const uint16_t* a, int Ca, const uint16_t* b, int Cb, uint16_t* out, int64_t tokens, hipStream_t st);
 hipError_t sd_cast_silu(const float* in, uint16_t* out, int64_t n, int silu, hipStream_t st);
-hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int HW, float mul, float add, int clamp01, hipStream_t st);
+hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int H, int W, float mul, float add, int clamp01,
+                             int in_pad, hipStream_t st);
 hipError_t sd_pointwise_small(const float* in, const float* w, const float* bias, float* out, int n, int C, int HW, float in_scale, hipStream_t st);
 hipError_t sd_cfg(const float* e, float* out, int64_t n, float g, hipStream_t st);
 hipError_t sd_lincomb(float* out, const float* sample, float cs, float ce, const float* e0, float c0, const float* e1, float c1,

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
                                                                  const uint16_t* __restrict__ K, int64_t ldk,
                                                                  const uint16_t* __restrict__ V, int64_t ldv,
                                                                  uint16_t* __restrict__ O, int64_t ldo, int Tq, int Tk,
-                                                                 int dh, float scale_log2) {
+                                                                 int dh, float scale_log2, int heads, int nqb) {
     using C = FaCfg<KS, DV>;
     __shared__ __attribute__((aligned(16))) char smem[C::KBYTES + C::VBYTES];
     char* ldsK = smem;
@@ -41,8 +41,13 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r16 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    // linear grid, XCD-contiguous: the 8 XCDs take workgroups round-robin, so consecutive blockIdx.x land on different
+    // XCDs; remapped, the query blocks of one (sample, head) -- which all stream the SAME keys / values -- run on one XCD
+    // and find them in its L2 after the first block's pass (speed only)
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bh = lin / nqb, qb = lin - bh * nqb;
+    const int b = bh / heads, h = bh - b * heads;
+    const int q0 = qb * 64 + wave * 16;
     const int dchunks = dh >> 3;                        // valid 16-byte chunks of a head row
 
     // ---- Q fragments (registers, whole kernel): lane holds Q[q][32 s + 8 g .. + 7]
@@ -60,8 +65,10 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
 
     const uint16_t* kbase = K + (int64_t)b * Tk * ldk + h * dh;
     const uint16_t* vbase = V + (int64_t)b * Tk * ldv + h * dh;
-    u32x4_t kreg[C::KIT], vreg[C::VIT];
-    auto prefetch = [&](int key0) {
+    // TWO register sets: tile t + 2 is requested while tile t is multiplied, so a key / value tile has two tile times
+    // (not one) to arrive from L2 -- one was measured latency-bound at head_dim 40 (a tile's arithmetic is ~0.15 us)
+    u32x4_t kregA[C::KIT], vregA[C::VIT], kregB[C::KIT], vregB[C::VIT];
+    auto prefetch = [&](int key0, u32x4_t (&kreg)[C::KIT], u32x4_t (&vreg)[C::VIT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::KIT; ++i) {
             const int idx = tid + i * 256;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
                 vreg[i] = *(const u32x4_t*)(vbase + (int64_t)(key0 + row) * ldv + c * 8);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const u32x4_t (&kreg)[C::KIT], const u32x4_t (&vreg)[C::VIT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::KIT; ++i) {
             const int idx = tid + i * 256;
@@ -104,12 +111,13 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (Tk + 63) >> 6;
-    prefetch(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    prefetch(0, kregA, vregA);
+    if (nkt > 1) prefetch(64, kregB, vregB);
+    auto tile = [&](int kt, u32x4_t (&kreg)[C::KIT], u32x4_t (&vreg)[C::VIT]) __attribute__((always_inline)) {
         __syncthreads();                       // every wave is done reading the previous tile
-        commit();
+        commit(kreg, vreg);
         __syncthreads();
-        if (kt + 1 < nkt) prefetch((kt + 1) * 64);      // in flight behind this tile's arithmetic
+        if (kt + 2 < nkt) prefetch((kt + 2) * 64, kreg, vreg);      // in flight behind two tiles' arithmetic
         const int key0 = kt * 64;
         // ---- S^T = K . Q^T for the 4 key sub-tiles of 16; keys >= Tk start at -inf
         f32x4_t s[4];
@@ -166,6 +174,10 @@ __global__ __launch_bounds__(256) void sd_flash_attention_kernel(const uint16_t*
                 o[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, o[md], 0, 0, 0);
             }
         }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, kregA, vregA);
+        if (kt + 1 < nkt) tile(kt + 1, kregB, vregB);
     }
     // ---- the lane groups hold disjoint keys of the same query: combine the row sums, normalise, store
     l_run += __shfl_xor(l_run, 16, 64);
@@ -191,9 +203,10 @@ template <int KS, int DV>
 hipError_t launch_fa(const uint16_t* Q, int64_t ldq, const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv,
                      uint16_t* O, int64_t ldo, int n, int heads, int Tq, int Tk, int dh, hipStream_t st) {
     const float scale_log2 = 1.4426950408889634f / sqrtf((float)dh);
-    dim3 grid((Tq + 63) / 64, heads, n);
+    const int nqb = (Tq + 63) / 64;
+    dim3 grid((unsigned)((int64_t)nqb * heads * n));
     hipLaunchKernelGGL((sd_flash_attention_kernel<KS, DV>), grid, dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, Tq, Tk, dh,
-                       scale_log2);
+                       scale_log2, heads, nqb);
     return hipGetLastError();
 }
 

@@ -19,6 +19,16 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 }
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
+// Token row of pixel t (= y * W + x) of image img.  Dense layout: img * HW + t.  PADDED layout (the operands and the
+// results of the 3x3 convolutions run as 9-plane GEMMs): every image is an (H + 2) x (W + 2) grid whose border rows are
+// zero in a convolution's input, so that tap (ky, kx) of a convolution is the same rows shifted by
+// (ky - 1) * (W + 2) + (kx - 1): no masking, no im2col.
+__device__ __forceinline__ int64_t tok_row(int64_t img, int t, int H, int W, int pad) {
+    if (!pad) return img * ((int64_t)H * W) + t;
+    const int y = t / W, x = t - y * W;
+    return img * ((int64_t)(H + 2) * (W + 2)) + (int64_t)(y + 1) * (W + 2) + (x + 1);
+}
+
 // ---- 3x3 convolution rows: out[(n, y, x), (ky, kx, c)] = in[n, y*s + ky - 1, x*s + kx - 1, c] (zero outside)
 // `up`: the source is the nearest-2x upsampling of `in` (Upsample2D + conv in one gather).  C % 8 == 0.
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
@@ -70,8 +80,9 @@ __global__ __launch_bounds__(256) void im2col_in_kernel(const float* __restrict_
 // ---- GroupNorm statistics: thread (token lane, group) walks the tokens of its slab; x' = x + tadd[n, c] (the
 // resnet's time projection, fp32 [n, ld_t]) when given.  part[n][slab][group] = {sum, sumsq} in a fixed order.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
-                                                         int64_t ld_t, float* __restrict__ part, int HW, int C, int groups,
-                                                         int slab_tokens, int nslab) {
+                                                         int64_t ld_t, float* __restrict__ part, int H, int W, int C, int groups,
+                                                         int slab_tokens, int nslab, int in_pad) {
+    const int HW = H * W;
     __shared__ float red[8][32][2];
     const int img = blockIdx.x / nslab, slab = blockIdx.x - img * nslab;
     const int g = threadIdx.x & 31, tl = threadIdx.x >> 5;
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
         const int t1 = min(HW, (slab + 1) * slab_tokens);
         const float* ta = tadd ? tadd + (int64_t)img * ld_t + g * cpg : nullptr;
         for (int t = slab * slab_tokens + tl; t < t1; t += 8) {
-            const uint16_t* p = x + ((int64_t)img * HW + t) * C + g * cpg;
+            const uint16_t* p = x + tok_row(img, t, H, W, in_pad) * C + g * cpg;
             for (int c = 0; c < cpg; c += 2) {        // cpg is even for every geometry here (checked on the host)
                 const uint32_t w = *(const uint32_t*)(p + c);
                 float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
@@ -120,19 +131,29 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU; 8 channels per thread
+// y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU; 8 channels per thread.  The thread space is the OUTPUT
+// layout's rows: with out_pad the border rows of every image are written as zeros (a convolution reads them as padding).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
                                                        int64_t ld_t, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       uint16_t* __restrict__ y, int n, int HW, int C, int groups, int silu) {
+                                                       uint16_t* __restrict__ y, int n, int H, int W, int C, int groups, int silu,
+                                                       int in_pad, int out_pad) {
     const int cv = C >> 3, cpg = C / groups;
-    const int64_t total = (int64_t)n * HW * cv;
+    const int Ho = out_pad ? H + 2 : H, Wo = out_pad ? W + 2 : W;
+    const int64_t total = (int64_t)n * Ho * Wo * cv;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(t % cv) * 8;
-        const int64_t tok = t / cv;
-        const int img = (int)(tok / HW);
+        const int64_t row = t / cv;
+        const int img = (int)(row / ((int64_t)Ho * Wo));
+        const int r = (int)(row - (int64_t)img * Ho * Wo);
+        int yy = r / Wo, xx = r - yy * Wo;
+        if (out_pad) { --yy; --xx; }
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+            ((u32x4_t*)y)[t] = u32x4_t{0u, 0u, 0u, 0u};
+            continue;
+        }
         float f[8];
-        unpack8(((const u32x4_t*)x)[t], f);
+        unpack8(*(const u32x4_t*)(x + tok_row(img, yy * W + xx, H, W, in_pad) * C + c0), f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c0 + i, g = c / cpg;
@@ -219,6 +240,44 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint16_t* __restric
     }
 }
 
+// ---- out[dense] = a[dense] + b[PADDED layout] (the residual add behind a resnet's second convolution)
+__global__ __launch_bounds__(256) void add_padded_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                         uint16_t* __restrict__ out, int n, int H, int W, int C) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)n * H * W * cv;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % cv);
+        const int64_t tok = t / cv;
+        const int img = (int)(tok / ((int64_t)H * W));
+        const int p = (int)(tok - (int64_t)img * H * W);
+        float x[8], y[8];
+        unpack8(((const u32x4_t*)a)[t], x);
+        unpack8(*(const u32x4_t*)(b + tok_row(img, p, H, W, 1) * C + c * 8), y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] += y[i];
+        ((u32x4_t*)out)[t] = pack8(x);
+    }
+}
+
+// ---- copy between the dense and the padded layout (borders of a padded output are zeroed)
+__global__ __launch_bounds__(256) void relayout_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int H,
+                                                       int W, int C, int in_pad, int out_pad) {
+    const int cv = C >> 3;
+    const int Ho = out_pad ? H + 2 : H, Wo = out_pad ? W + 2 : W;
+    const int64_t total = (int64_t)n * Ho * Wo * cv;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % cv);
+        const int64_t row = t / cv;
+        const int img = (int)(row / ((int64_t)Ho * Wo));
+        const int r = (int)(row - (int64_t)img * Ho * Wo);
+        int yy = r / Wo, xx = r - yy * Wo;
+        if (out_pad) { --yy; --xx; }
+        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const u32x4_t*)(in + tok_row(img, yy * W + xx, H, W, in_pad) * C + c * 8);
+        ((u32x4_t*)out)[t] = v;
+    }
+}
+
 // ---- channel concatenation of two token-major tensors: out[t] = a[t] | b[t]
 __global__ __launch_bounds__(256) void concat_kernel(const uint16_t* __restrict__ a, int Ca, const uint16_t* __restrict__ b,
                                                      int Cb, uint16_t* __restrict__ out, int64_t tokens) {
@@ -242,14 +301,16 @@ __global__ __launch_bounds__(256) void cast_silu_kernel(const float* __restrict_
 
 // ---- fp32 token-major [n * HW, ld] (first C columns) -> fp32 NCHW [n, C, H, W]; out = in * mul + add, optional clamp
 __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
-                                                             int n, int C, int HW, float mul, float add, int clamp01) {
+                                                             int n, int C, int H, int W, float mul, float add, int clamp01,
+                                                             int in_pad) {
+    const int HW = H * W;
     const int64_t total = (int64_t)n * C * HW;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int p = (int)(t % HW);
         int64_t r = t / HW;
         const int c = (int)(r % C);
         const int64_t img = r / C;
-        float v = in[(img * HW + p) * ld + c] * mul + add;
+        float v = in[tok_row(img, p, H, W, in_pad) * ld + c] * mul + add;
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         out[t] = v;
     }
@@ -432,18 +493,34 @@ size_t sd_groupnorm_ws_floats(int n, int HW, int groups) {
     return (size_t)n * nslab * groups * 2 + (size_t)n * groups * 2;
 }
 
+// in_pad / out_pad: the input / output is in the padded layout (tok_row); the output's border rows are zeroed
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
-                        int n, int HW, int C, int groups, float eps, int silu, float* ws, hipStream_t st) {
+                        int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
+                        hipStream_t st) {
     if (groups > 32 || C % groups != 0 || (C / groups) % 2 != 0 || C % 8 != 0) return hipErrorInvalidValue;
-    const int slab = 256;
+    const int slab = 256, HW = H * W;
     const int nslab = (HW + slab - 1) / slab;
     float* part = ws;
     float* stats = ws + (size_t)n * nslab * groups * 2;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), 0, st, x, tadd, ld_t, part, HW, C, groups, slab, nslab);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), 0, st, x, tadd, ld_t, part, H, W, C, groups, slab, nslab, in_pad);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 63) / 64), dim3(64), 0, st, part, stats, nslab, groups,
                        (double)HW * (C / groups), eps, n * groups);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((int64_t)n * HW * (C >> 3))), dim3(256), 0, st, x, tadd, ld_t, stats, gamma,
-                       beta, y, n, HW, C, groups, silu);
+    const int64_t rows = out_pad ? (int64_t)n * (H + 2) * (W + 2) : (int64_t)n * HW;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, st, x, tadd, ld_t, stats, gamma,
+                       beta, y, n, H, W, C, groups, silu, in_pad, out_pad);
+    return hipGetLastError();
+}
+
+hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, hipStream_t st) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const int64_t rows = out_pad ? (int64_t)n * (H + 2) * (W + 2) : (int64_t)n * H * W;
+    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, st, in, out, n, H, W, C, in_pad, out_pad);
+    return hipGetLastError();
+}
+
+hipError_t sd_add_padded(const uint16_t* a, const uint16_t* b_padded, uint16_t* out, int n, int H, int W, int C, hipStream_t st) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_padded_kernel, dim3(grid_for((int64_t)n * H * W * (C >> 3))), dim3(256), 0, st, a, b_padded, out, n, H, W, C);
     return hipGetLastError();
 }
 
@@ -478,10 +555,10 @@ hipError_t sd_cast_silu(const float* in, uint16_t* out, int64_t n, int silu, hip
     return hipGetLastError();
 }
 
-hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int HW, float mul, float add, int clamp01,
-                             hipStream_t st) {
-    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(grid_for((int64_t)n * C * HW)), dim3(256), 0, st, in, ld, out, n, C, HW, mul, add,
-                       clamp01);
+hipError_t sd_tokens_to_nchw(const float* in, int64_t ld, float* out, int n, int C, int H, int W, float mul, float add, int clamp01,
+                             int in_pad, hipStream_t st) {
+    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(grid_for((int64_t)n * C * H * W)), dim3(256), 0, st, in, ld, out, n, C, H, W, mul,
+                       add, clamp01, in_pad);
     return hipGetLastError();
 }
 

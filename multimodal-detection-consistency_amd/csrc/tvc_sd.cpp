@@ -40,7 +40,9 @@ namespace {
 struct Act {             // bf16 token-major activation
     uint16_t* p = nullptr;
     int n = 0, H = 0, W = 0, C = 0;
+    bool pad = false;    // PADDED layout (sd_ops.hip, tok_row): (H + 2) x (W + 2) rows per image -- what the 9-plane conv GEMM reads / writes
     int64_t tok() const { return (int64_t)n * H * W; }
+    int64_t rows() const { return pad ? (int64_t)n * (H + 2) * (W + 2) : tok(); }
 };
 
 // One evaluation: arena bump allocator + first-error latch (after an error every op is a no-op).
@@ -71,6 +73,13 @@ struct Run {
         a.p = (uint16_t*)alloc((size_t)rows * C * 2);
         return a;
     }
+    // padded layout: + the rows a shifted tap reads beyond the last tile
+    Act act_padded(int n, int H, int W, int C) {
+        Act a; a.n = n; a.H = H; a.W = W; a.C = C; a.pad = true;
+        const int64_t rows = (a.rows() + 255) / 256 * 256 + 256 + 3 * (W + 2);
+        a.p = (uint16_t*)alloc((size_t)rows * C * 2);
+        return a;
+    }
     const void* W(const std::string& name) {
         auto it = S->w.find(name);
         if (it == S->w.end()) {
@@ -87,7 +96,37 @@ struct Run {
         GemmLaunch g;
         g.A = (const uint16_t*)A; g.lda = K; g.I = I; g.B = B; g.ldb = K; g.J = (int)J; g.K = K;
         g.bias = bias; g.out = out; g.ldo = ldo; g.epilogue = epi; g.b_rows_padded = true;
+        g.a_rows_padded = true;            // tvc_sd_load's contract: GEMM weights are readable to the next multiple of 256 rows
         hip(timed_gemm(h, g, st), "sd gemm");
+    }
+    // 3x3 convolution, stride 1, padding 1, as ONE GEMM of 9 K-planes: xp is in the padded layout with ZERO border rows
+    // (a GroupNorm output), so tap (ky, kx) is the same token rows shifted by ky * (W + 2) + kx -- no im2col rows, the
+    // activations are read once (from L2 for eight of the nine taps).  Output row q = input row q + (W + 3) (the tap
+    // centre), i.e. the result is in the padded layout too; its border rows hold garbage nobody reads.
+    // out_f32: fp32 output [rows, Cout] (the model's last convolution) instead of a bf16 activation.
+    Act conv3x3_planes(const Act& xp, const std::string& prefix, int Cout, float** out_f32 = nullptr) {
+        Act y;
+        float* of = nullptr;
+        if (out_f32) {
+            y = xp; y.C = Cout; y.p = nullptr;
+            of = (float*)alloc((size_t)(xp.rows() + 256) * Cout * 4);
+            *out_f32 = of;
+        } else {
+            y = act_padded(xp.n, xp.H, xp.W, Cout);
+        }
+        const void* w = W(prefix + "weight");
+        const float* b = (const float*)W(prefix + "bias");
+        if (!live()) return y;
+        const int Wp = xp.W + 2;
+        GemmLaunch g;
+        g.A = (const uint16_t*)w; g.lda = 9 * (int64_t)xp.C; g.I = Cout; g.B = xp.p; g.ldb = xp.C;
+        g.J = (int)(xp.rows() - 2 * (Wp + 1)); g.K = xp.C; g.planes = 9;
+        for (int t = 0; t < 9; ++t) { g.a_plane_off[t] = t * xp.C; g.b_plane_off[t] = ((t / 3) * Wp + t % 3) * xp.C; }
+        g.bias = b; g.ldo = Cout; g.b_rows_padded = true; g.a_rows_padded = true;
+        if (out_f32) { g.out = of + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_F32; }
+        else { g.out = y.p + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_BF16; }
+        hip(timed_gemm(h, g, st), "sd conv gemm");
+        return y;
     }
     // linear / 1x1 convolution on token rows
     Act linear(const Act& x, const std::string& wname, const std::string& bname, int Cout) {
@@ -114,15 +153,17 @@ struct Run {
         off = mark;
         return y;
     }
-    Act groupnorm(const Act& x, const std::string& prefix, float eps, int silu, const float* tadd = nullptr, int64_t ld_t = 0) {
-        Act y = act(x.n, x.H, x.W, x.C);
+    Act groupnorm(const Act& x, const std::string& prefix, float eps, int silu, const float* tadd = nullptr, int64_t ld_t = 0,
+                  bool out_pad = false) {
+        Act y = out_pad ? act_padded(x.n, x.H, x.W, x.C) : act(x.n, x.H, x.W, x.C);
         const size_t mark = off;
         float* ws = (float*)alloc(sd_groupnorm_ws_floats(x.n, x.H * x.W, S->d.norm_groups) * 4);
         const float* g = (const float*)W(prefix + "weight");
         const float* b = (const float*)W(prefix + "bias");
         if (live()) {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)x.tok() * x.C * 6.0);
-            hip(sd_groupnorm(x.p, tadd, ld_t, g, b, y.p, x.n, x.H * x.W, x.C, S->d.norm_groups, eps, silu, ws, st), "sd_groupnorm");
+            hip(sd_groupnorm(x.p, tadd, ld_t, g, b, y.p, x.n, x.H, x.W, x.C, S->d.norm_groups, eps, silu, x.pad, out_pad, ws, st),
+                "sd_groupnorm");
         }
         off = mark;
         return y;
@@ -156,21 +197,21 @@ struct Run {
     Act resnet(const Act& x, const std::string& p, int Cout, const float* tadd_all, float eps) {
         Act out = act(x.n, x.H, x.W, Cout);
         const size_t mark = off;
-        Act h1 = groupnorm(x, p + "norm1.", eps, 1);
-        Act h2 = conv3x3(h1, p + "conv1.", Cout);
+        Act h1 = groupnorm(x, p + "norm1.", eps, 1, nullptr, 0, true);
+        Act h2 = conv3x3_planes(h1, p + "conv1.", Cout);
         const float* tadd = nullptr;
         if (tadd_all) {
             auto it = S->temb_off.find(p);
             if (it == S->temb_off.end()) { if (rc == TVC_OK) rc = fail(h, TVC_E_STATE, "tvc_sd: no time projection for " + p); }
             else tadd = tadd_all + it->second;
         }
-        Act h3 = groupnorm(h2, p + "norm2.", eps, 1, tadd, S->temb_total);
-        Act h4 = conv3x3(h3, p + "conv2.", Cout);
+        Act h3 = groupnorm(h2, p + "norm2.", eps, 1, tadd, S->temb_total, true);
+        Act h4 = conv3x3_planes(h3, p + "conv2.", Cout);
         Act sc = x;
         if (x.C != Cout) sc = linear(x, p + "conv_shortcut.weight", p + "conv_shortcut.bias", Cout);
         if (live()) {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)x.tok() * Cout * 6.0);
-            hip(sd_add_bf16(sc.p, h4.p, out.p, out.tok() * Cout, st), "sd_add");
+            hip(sd_add_padded(sc.p, h4.p, out.p, x.n, x.H, x.W, Cout, st), "sd_add_padded");
         }
         off = mark;
         return out;
@@ -321,14 +362,11 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
         }
         if (i != nb - 1) x = R.conv3x3(x, pi + ".upsamplers.0.conv.", c, 1, 1);
     }
-    Act y = R.groupnorm(x, "conv_norm_out.", eps, 1);
+    Act y = R.groupnorm(x, "conv_norm_out.", eps, 1, nullptr, 0, true);
     {
-        Act col = R.act(n, H, W, 9 * y.C);
-        float* o = (float*)R.alloc((size_t)n * H * W * d.out_channels * 4);
-        if (R.live()) R.hip(sd_im2col3x3(y.p, col.p, n, H, W, y.C, 1, 0, R.st), "sd_im2col3x3");
-        R.gemm(R.W("conv_out.weight"), d.out_channels, 9 * y.C, col.p, col.tok(), (const float*)R.W("conv_out.bias"), o,
-               d.out_channels, TVC_EPI_F32);
-        if (R.live()) R.hip(sd_tokens_to_nchw(o, d.out_channels, eps_out, n, d.out_channels, H * W, 1.0f, 0.0f, 0, R.st), "to nchw");
+        float* o = nullptr;
+        R.conv3x3_planes(y, "conv_out.", d.out_channels, &o);
+        if (R.live()) R.hip(sd_tokens_to_nchw(o, d.out_channels, eps_out, n, d.out_channels, H, W, 1.0f, 0.0f, 0, 1, R.st), "to nchw");
     }
 }
 
@@ -361,12 +399,10 @@ void vae_forward(Run& R, const float* latents, int n, int H, int W, float* image
         for (int j = 0; j < d.vae_layers_per_block + 1; ++j) x = R.resnet(x, pi + ".resnets." + std::to_string(j) + ".", c, nullptr, eps);
         if (i != nb - 1) x = R.conv3x3(x, pi + ".upsamplers.0.conv.", c, 1, 1);
     }
-    Act y = R.groupnorm(x, "decoder.conv_norm_out.", eps, 1);
-    Act col = R.act(y.n, y.H, y.W, 9 * y.C);
-    float* o = (float*)R.alloc((size_t)y.tok() * 3 * 4);
-    if (R.live()) R.hip(sd_im2col3x3(y.p, col.p, y.n, y.H, y.W, y.C, 1, 0, R.st), "sd_im2col3x3");
-    R.gemm(R.W("decoder.conv_out.weight"), 3, 9 * y.C, col.p, col.tok(), (const float*)R.W("decoder.conv_out.bias"), o, 3, TVC_EPI_F32);
-    if (R.live()) R.hip(sd_tokens_to_nchw(o, 3, images, y.n, 3, y.H * y.W, 0.5f, 0.5f, 1, R.st), "to nchw");
+    Act y = R.groupnorm(x, "decoder.conv_norm_out.", eps, 1, nullptr, 0, true);
+    float* o = nullptr;
+    R.conv3x3_planes(y, "decoder.conv_out.", 3, &o);
+    if (R.live()) R.hip(sd_tokens_to_nchw(o, 3, images, y.n, 3, y.H, y.W, 0.5f, 0.5f, 1, 1, R.st), "to nchw");
 }
 
 // run `body` twice: a dry pass that sizes the arena, then the real one
@@ -624,6 +660,13 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
             y = R.transformer(x, p, ctx16);
         } else if (kind == 2) {
             y = R.vae_attention(x, p);
+        } else if (kind == 3) {
+            // stride 1: the 9-plane GEMM on the padded layout (dense -> padded with zero borders -> conv -> dense)
+            Act xp = R.act_padded(n, H, W, Cin);
+            if (R.live()) R.hip(sd_relayout(x.p, xp.p, n, H, W, Cin, 0, 1, R.st), "relayout");
+            Act yp = R.conv3x3_planes(xp, p, Cout);
+            y = R.act(n, H, W, Cout);
+            if (R.live()) R.hip(sd_relayout(yp.p, y.p, n, H, W, Cout, 1, 0, R.st), "relayout");
         } else {
             y = R.conv3x3(x, p, Cout, kind == 4 ? 2 : 1, kind == 5 ? 1 : 0);
         }

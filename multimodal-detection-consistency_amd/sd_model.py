@@ -45,7 +45,12 @@ def prepare_sd_tensors(unet_w: Optional[Dict[str, torch.Tensor]], vae_w: Optiona
     out: Dict[str, torch.Tensor] = {}
 
     def put(name: str, t: torch.Tensor, dtype) -> None:
-        out[name] = t.detach().to(device=device, dtype=dtype).contiguous()
+        t = t.detach().to(dtype=dtype)
+        if dtype == torch.bfloat16 and t.dim() == 2 and t.shape[0] % 256:
+            # tvc_sd_load's contract: GEMM weights are readable up to the next multiple of 256 rows (zero rows), so the
+            # fast GEMM form stages whole 256-row tiles even where the width (320, 640, 4 ...) is not a multiple of 256
+            t = torch.cat([t, t.new_zeros((256 - t.shape[0] % 256, t.shape[1]))])
+        out[name] = t.to(device=device).contiguous()
 
     for w in (unet_w or {}), (vae_w or {}):
         fused = set()

@@ -632,7 +632,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         int S = ntiles > 0 ? 256 / ntiles : 0;
         if (S > nk64 / 2) S = nk64 / 2;
         if (S > 16) S = 16;
-        if (small_on && forced < 0 && L.splitk_ws && S >= 2 &&
+        if ((small_on || L.splitk_small) && forced < 0 && L.splitk_ws && S >= 2 &&
             (size_t)ntiles * S * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes) {
             hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(ntiles * S), block, GEMM_LDS_BYTES, stream, g,
                                L.splitk_ws, nIt, 0, S);

@@ -14,6 +14,8 @@ struct GemmLaunch {
     int planes = 1;
     int a_plane_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // up to GEMM_MAX_PLANES
     int b_plane_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool splitk_small = false;     // launches of fewer tiles than CUs may split K over the idle CUs (needs splitk_ws; the fp32 sums are
+                                   // then taken in a different order than in the one-pass kernels)
     bool a_rows_padded = false;    // A has readable rows up to the next multiple of 256 beyond I (form 4 with a ragged last row tile)
     const float* bias = nullptr;   // [I]
     void* out = nullptr;           // [J, ldo]

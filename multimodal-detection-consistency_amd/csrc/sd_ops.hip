@@ -77,62 +77,78 @@ __global__ __launch_bounds__(256) void im2col_in_kernel(const float* __restrict_
     }
 }
 
-// ---- GroupNorm statistics: thread (token lane, group) walks the tokens of its slab; x' = x + tadd[n, c] (the
-// resnet's time projection, fp32 [n, ld_t]) when given.  part[n][slab][group] = {sum, sumsq} in a fixed order.
+// ---- GroupNorm statistics.  Thread (token lane tl, 8-channel vector v) walks the tokens tl, tl + lanes, ... of its slab
+// with 16-byte loads (a wave reads whole rows) and keeps per-channel sums in registers; the per-channel sums of all token
+// lanes meet in LDS, thread g then adds its group's channels in a fixed order: part[n][slab][group] = {sum, sumsq}.
+// x' = x + tadd[n, c] (the resnet's time projection, fp32 [n, ld_t]) when given.  C % 8 == 0, C <= 4096.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
                                                          int64_t ld_t, float* __restrict__ part, int H, int W, int C, int groups,
                                                          int slab_tokens, int nslab, int in_pad) {
+    extern __shared__ __attribute__((aligned(16))) float gn_red[];      // [lanes][C][2]
     const int HW = H * W;
-    __shared__ float red[8][32][2];
     const int img = blockIdx.x / nslab, slab = blockIdx.x - img * nslab;
-    const int g = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int cpg = C / groups;
-    float s = 0.f, q = 0.f;
-    if (g < groups) {
-        const int t1 = min(HW, (slab + 1) * slab_tokens);
-        const float* ta = tadd ? tadd + (int64_t)img * ld_t + g * cpg : nullptr;
-        for (int t = slab * slab_tokens + tl; t < t1; t += 8) {
-            const uint16_t* p = x + tok_row(img, t, H, W, in_pad) * C + g * cpg;
-            for (int c = 0; c < cpg; c += 2) {        // cpg is even for every geometry here (checked on the host)
-                const uint32_t w = *(const uint32_t*)(p + c);
-                float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xffff0000u);
-                if (ta) { a += ta[c]; b += ta[c + 1]; }
-                s += a + b;
-                q += a * a + b * b;
+    const int cv = C >> 3;
+    const int Wv = cv < 256 ? cv : 256;          // vector columns handled side by side
+    const int lanes = 256 / Wv;                  // token lanes
+    const int tl = threadIdx.x / Wv, v0 = threadIdx.x - tl * Wv;
+    const int t0 = slab * slab_tokens, t1 = min(HW, t0 + slab_tokens);
+    if (tl < lanes) {
+        for (int v = v0; v < cv; v += Wv) {
+            float s[8], q[8], ta[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; ta[i] = tadd ? tadd[(int64_t)img * ld_t + v * 8 + i] : 0.f; }
+            for (int t = t0 + tl; t < t1; t += lanes) {
+                float f[8];
+                unpack8(*(const u32x4_t*)(x + tok_row(img, t, H, W, in_pad) * C + v * 8), f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float a = f[i] + ta[i]; s[i] += a; q[i] += a * a; }
             }
+            float* o = gn_red + ((size_t)tl * C + v * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o[2 * i] = s[i]; o[2 * i + 1] = q[i]; }
         }
     }
-    red[tl][g][0] = s; red[tl][g][1] = q;
     __syncthreads();
-    if (tl == 0 && g < groups) {
+    const int g = threadIdx.x;
+    if (g < groups) {
+        const int cpg = C / groups;
         float ss = 0.f, qq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { ss += red[i][g][0]; qq += red[i][g][1]; }
+        for (int l = 0; l < lanes; ++l) {
+            const float* r = gn_red + ((size_t)l * C + g * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) { ss += r[2 * c]; qq += r[2 * c + 1]; }
+        }
         float* o = part + (((int64_t)img * nslab + slab) * groups + g) * 2;
         o[0] = ss; o[1] = qq;
     }
 }
 
-// stats[n][group] = {mean, rstd}
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nslab,
-                                                         int groups, double count, float eps, int total) {
-    const int i = blockIdx.x * 64 + threadIdx.x;          // (img, group)
+// stats[n][group] = {mean, rstd}: one wave per (image, group), the slabs' partials summed in fp64
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nslab,
+                                                          int groups, double count, float eps, int total) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);    // (img, group)
+    const int lane = threadIdx.x & 63;
     if (i >= total) return;
     const int img = i / groups, g = i - img * groups;
     double s = 0.0, q = 0.0;
-    for (int sl = 0; sl < nslab; ++sl) {
+    for (int sl = lane; sl < nslab; sl += 64) {
         const float* p = part + (((int64_t)img * nslab + sl) * groups + g) * 2;
         s += p[0]; q += p[1];
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[i * 2] = (float)mean;
-    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[i * 2] = (float)mean;
+        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
-// y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU; 8 channels per thread.  The thread space is the OUTPUT
-// layout's rows: with out_pad the border rows of every image are written as zeros (a convolution reads them as padding).
+// y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU.  One workgroup per OUTPUT row y of one image (with
+// out_pad the two border rows and the border columns are written as zeros: a convolution reads them as padding); thread
+// (pixel lane, 8-channel vector) keeps its vector's scale / shift -- rstd * gamma and beta + (tadd - mean) * rstd * gamma
+// -- in registers and walks the row's pixels: one fma (+ SiLU) per element, no integer division in the loop.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
                                                        int64_t ld_t, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -140,29 +156,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
                                                        int in_pad, int out_pad) {
     const int cv = C >> 3, cpg = C / groups;
     const int Ho = out_pad ? H + 2 : H, Wo = out_pad ? W + 2 : W;
-    const int64_t total = (int64_t)n * Ho * Wo * cv;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(t % cv) * 8;
-        const int64_t row = t / cv;
-        const int img = (int)(row / ((int64_t)Ho * Wo));
-        const int r = (int)(row - (int64_t)img * Ho * Wo);
-        int yy = r / Wo, xx = r - yy * Wo;
-        if (out_pad) { --yy; --xx; }
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
-            ((u32x4_t*)y)[t] = u32x4_t{0u, 0u, 0u, 0u};
-            continue;
-        }
-        float f[8];
-        unpack8(*(const u32x4_t*)(x + tok_row(img, yy * W + xx, H, W, in_pad) * C + c0), f);
+    const int img = blockIdx.x / Ho, yo = blockIdx.x - img * Ho;
+    const int yy = out_pad ? yo - 1 : yo;
+    const int Wv = cv < 256 ? cv : 256;
+    const int lanes = 256 / Wv;
+    const int tl = threadIdx.x / Wv, v0 = threadIdx.x - tl * Wv;
+    if (tl >= lanes) return;
+    uint16_t* yrow = y + ((int64_t)img * Ho + yo) * Wo * C;
+    if (yy < 0 || yy >= H) {                     // a border row of the padded layout
+        for (int v = v0; v < cv; v += Wv)
+            for (int xo = tl; xo < Wo; xo += lanes) *(u32x4_t*)(yrow + (int64_t)xo * C + v * 8) = u32x4_t{0u, 0u, 0u, 0u};
+        return;
+    }
+    const uint16_t* xrow = x + tok_row(img, yy * W, H, W, in_pad) * C;       // pixel (yy, 0); a row's pixels are consecutive rows
+    for (int v = v0; v < cv; v += Wv) {
+        float sc[8], sh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c = c0 + i, g = c / cpg;
-            float v = f[i];
-            if (tadd) v += tadd[(int64_t)img * ld_t + c];
-            v = (v - stats[(img * groups + g) * 2]) * stats[(img * groups + g) * 2 + 1] * gamma[c] + beta[c];
-            f[i] = silu ? silu_f(v) : v;
+            const int c = v * 8 + i, g = c / cpg;
+            const float mean = stats[(img * groups + g) * 2], rstd = stats[(img * groups + g) * 2 + 1];
+            sc[i] = rstd * gamma[c];
+            sh[i] = beta[c] + ((tadd ? tadd[(int64_t)img * ld_t + c] : 0.f) - mean) * sc[i];
         }
-        ((u32x4_t*)y)[t] = pack8(f);
+        for (int xo = tl; xo < Wo; xo += lanes) {
+            const int xx = out_pad ? xo - 1 : xo;
+            u32x4_t o = u32x4_t{0u, 0u, 0u, 0u};
+            if (xx >= 0 && xx < W) {
+                float f[8];
+                unpack8(*(const u32x4_t*)(xrow + (int64_t)xx * C + v * 8), f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float val = fmaf(f[i], sc[i], sh[i]);
+                    f[i] = silu ? silu_f(val) : val;
+                }
+                o = pack8(f);
+            }
+            *(u32x4_t*)(yrow + (int64_t)xo * C + v * 8) = o;
+        }
     }
 }
 
@@ -487,27 +517,31 @@ hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, i
 }
 
 // ws: >= n * nslab * groups * 2 + n * groups * 2 floats (sd_groupnorm_ws_floats)
+static int gn_slab_tokens(int HW);
 size_t sd_groupnorm_ws_floats(int n, int HW, int groups) {
-    const int slab = 256;
+    const int slab = gn_slab_tokens(HW);
     const int nslab = (HW + slab - 1) / slab;
     return (size_t)n * nslab * groups * 2 + (size_t)n * groups * 2;
 }
 
 // in_pad / out_pad: the input / output is in the padded layout (tok_row); the output's border rows are zeroed
+static int gn_slab_tokens(int HW) { int s = 256; while ((HW + s - 1) / s > 256) s *= 2; return s; }
+
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
                         int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
                         hipStream_t st) {
-    if (groups > 32 || C % groups != 0 || (C / groups) % 2 != 0 || C % 8 != 0) return hipErrorInvalidValue;
-    const int slab = 256, HW = H * W;
+    if (groups > 32 || C % groups != 0 || C % 8 != 0 || C > 4096) return hipErrorInvalidValue;
+    const int HW = H * W, slab = gn_slab_tokens(HW);
     const int nslab = (HW + slab - 1) / slab;
     float* part = ws;
     float* stats = ws + (size_t)n * nslab * groups * 2;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), 0, st, x, tadd, ld_t, part, H, W, C, groups, slab, nslab, in_pad);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 63) / 64), dim3(64), 0, st, part, stats, nslab, groups,
+    const int cv = C >> 3, Wv = cv < 256 ? cv : 256, lanes = 256 / Wv;
+    const size_t lds = (size_t)lanes * C * 2 * 4;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), lds, st, x, tadd, ld_t, part, H, W, C, groups, slab, nslab, in_pad);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 3) / 4), dim3(256), 0, st, part, stats, nslab, groups,
                        (double)HW * (C / groups), eps, n * groups);
-    const int64_t rows = out_pad ? (int64_t)n * (H + 2) * (W + 2) : (int64_t)n * HW;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, st, x, tadd, ld_t, stats, gamma,
-                       beta, y, n, H, W, C, groups, silu, in_pad, out_pad);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(n * (out_pad ? H + 2 : H)), dim3(256), 0, st, x, tadd, ld_t, stats, gamma, beta, y, n,
+                       H, W, C, groups, silu, in_pad, out_pad);
     return hipGetLastError();
 }
 

@@ -54,6 +54,8 @@ struct Run {
     char* base = nullptr;
     size_t off = 0, high = 0;
     int rc = TVC_OK;
+    float* splitk = nullptr;          // fp32 partial tiles for the split-K form of GEMMs with fewer tiles than CUs
+    static constexpr size_t SPLITK_BYTES = (size_t)256 * 256 * 256 * 4;
 
     bool live() const { return rc == TVC_OK && !dry; }
     void hip(hipError_t e, const char* what) {
@@ -97,6 +99,8 @@ struct Run {
         g.A = (const uint16_t*)A; g.lda = K; g.I = I; g.B = B; g.ldb = K; g.J = (int)J; g.K = K;
         g.bias = bias; g.out = out; g.ldo = ldo; g.epilogue = epi; g.b_rows_padded = true;
         g.a_rows_padded = true;            // tvc_sd_load's contract: GEMM weights are readable to the next multiple of 256 rows
+        // the 16 x 16 / 8 x 8 levels and the time / text projections are a few tiles with a long K: split it over the idle CUs
+        g.splitk_small = true; g.splitk_ws = splitk; g.splitk_ws_bytes = splitk ? SPLITK_BYTES : 0;
         hip(timed_gemm(h, g, st), "sd gemm");
     }
     // 3x3 convolution, stride 1, padding 1, as ONE GEMM of 9 K-planes: xp is in the padded layout with ZERO border rows
@@ -123,6 +127,7 @@ struct Run {
         g.J = (int)(xp.rows() - 2 * (Wp + 1)); g.K = xp.C; g.planes = 9;
         for (int t = 0; t < 9; ++t) { g.a_plane_off[t] = t * xp.C; g.b_plane_off[t] = ((t / 3) * Wp + t % 3) * xp.C; }
         g.bias = b; g.ldo = Cout; g.b_rows_padded = true; g.a_rows_padded = true;
+        g.splitk_small = true; g.splitk_ws = splitk; g.splitk_ws_bytes = splitk ? SPLITK_BYTES : 0;
         if (out_f32) { g.out = of + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_F32; }
         else { g.out = y.p + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_BF16; }
         hip(timed_gemm(h, g, st), "sd conv gemm");
@@ -409,12 +414,14 @@ void vae_forward(Run& R, const float* latents, int n, int H, int W, float* image
 template <class F>
 int with_arena(tvc_handle* h, hipStream_t st, Slot slot, F&& body) {
     Run dry{h, h->sd, st, true};
+    dry.splitk = (float*)dry.alloc(Run::SPLITK_BYTES);
     body(dry);
     if (dry.rc != TVC_OK) return dry.rc;
     int rc = ensure(h, slot, dry.high + 4096);
     if (rc) return rc;
     Run run{h, h->sd, st, false};
     run.base = (char*)h->ws[slot].p;
+    run.splitk = (float*)run.alloc(Run::SPLITK_BYTES);
     body(run);
     return run.rc;
 }
@@ -440,9 +447,11 @@ int tvc_sd_load(tvc_handle* h, const tvc_sd_desc* desc, const tvc_named_tensor* 
         return fail(h, TVC_E_INVALID, "tvc_sd_load: unsupported geometry");
     for (int i = 0; i < d.n_blocks; ++i) {
         const int c = d.block_out_channels[i];
-        if (c % 64 != 0 || c % d.norm_groups != 0 || (c / d.norm_groups) % 2 != 0 || c % d.heads != 0 || (c / d.heads) % 8 != 0 ||
-            c / d.heads > 160 || c > 1536)
-            return fail(h, TVC_E_INVALID, "tvc_sd_load: UNet widths must be multiples of 64, head_dim a multiple of 8 up to 160");
+        const int dh = c % d.heads == 0 ? c / d.heads : 0;
+        const bool dh_ok = dh == 8 || dh == 16 || dh == 24 || dh == 32 || dh == 40 || dh == 48 || dh == 56 || dh == 64 || dh == 80 ||
+                           dh == 96 || dh == 128 || dh == 160;         // the instantiations of sd_flash_attention_kernel
+        if (c % 64 != 0 || c % d.norm_groups != 0 || (c / d.norm_groups) % 2 != 0 || !dh_ok || c > 1536)
+            return fail(h, TVC_E_INVALID, "tvc_sd_load: UNet widths must be multiples of 64 with head_dim in {8..64 step 8, 80, 96, 128, 160}");
     }
     for (int i = 0; i < d.vae_n_blocks; ++i) {
         const int c = d.vae_block_out_channels[i];

@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02a
+O=gpurun_out/${ROUND:-r03}a
 mkdir -p $O
 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
 tail -c 3000 $O/bench.json
@@ -19,3 +19,6 @@ rocprofv3 --pmc WRITE_SIZE -d $O/cal_w -o w --output-format csv -- python3 scrip
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/cal_r -o r --output-format csv -- python3 scripts/pmc_calibrate.py > $O/cal_r.log 2>&1 || echo "cal r failed"
 rocprofv3 -L > $O/counters.txt 2>&1 || true
 find $O -name "*.csv" | head -30
+echo "--- SD reference generator: kernel trace of one batched generation (12 images, 20 steps, 64 x 64 latents + VAE)"
+rocprofv3 --kernel-trace --stats -d $O/sd_ktrace -o sd --output-format csv -- python3 scripts/sd_profile.py 20 > $O/sd_profile.json 2> $O/sd_profile.err || echo "sd trace failed"
+tail -1 $O/sd_profile.json

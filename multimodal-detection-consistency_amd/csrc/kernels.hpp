@@ -157,7 +157,7 @@ size_t sd_groupnorm_ws_floats(int n, int HW, int groups);
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
                         int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
                         hipStream_t st);
-hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, hipStream_t st);
+hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, int up, hipStream_t st);
 hipError_t sd_add_padded(const uint16_t* a, const uint16_t* b_padded, uint16_t* out, int n, int H, int W, int C, hipStream_t st);
 hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps, hipStream_t st);
 hipError_t sd_geglu(const uint16_t* in, uint16_t* out, int64_t rows, int Ch, hipStream_t st);

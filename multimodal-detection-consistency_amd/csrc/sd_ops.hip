@@ -97,7 +97,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
             float s[8], q[8], ta[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; ta[i] = tadd ? tadd[(int64_t)img * ld_t + v * 8 + i] : 0.f; }
-            for (int t = t0 + tl; t < t1; t += lanes) {
+            int t = t0 + tl;
+            for (; t + lanes < t1; t += 2 * lanes) {           // two rows in flight
+                const u32x4_t r0 = *(const u32x4_t*)(x + tok_row(img, t, H, W, in_pad) * C + v * 8);
+                const u32x4_t r1 = *(const u32x4_t*)(x + tok_row(img, t + lanes, H, W, in_pad) * C + v * 8);
+                float f[8], h8[8];
+                unpack8(r0, f);
+                unpack8(r1, h8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = f[i] + ta[i], b2 = h8[i] + ta[i];
+                    s[i] += a + b2; q[i] += a * a + b2 * b2;
+                }
+            }
+            for (; t < t1; t += lanes) {
                 float f[8];
                 unpack8(*(const u32x4_t*)(x + tok_row(img, t, H, W, in_pad) * C + v * 8), f);
 #pragma unroll
@@ -289,11 +302,13 @@ __global__ __launch_bounds__(256) void add_padded_kernel(const uint16_t* __restr
     }
 }
 
-// ---- copy between the dense and the padded layout (borders of a padded output are zeroed)
+// ---- copy between the dense and the padded layout (borders of a padded output are zeroed); up: the output is the
+// nearest-2x upsampling of the input (H, W = the OUTPUT's extent; Upsample2D in front of a 9-plane convolution)
 __global__ __launch_bounds__(256) void relayout_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int H,
-                                                       int W, int C, int in_pad, int out_pad) {
+                                                       int W, int C, int in_pad, int out_pad, int up) {
     const int cv = C >> 3;
     const int Ho = out_pad ? H + 2 : H, Wo = out_pad ? W + 2 : W;
+    const int Hi = up ? H >> 1 : H, Wi = up ? W >> 1 : W;
     const int64_t total = (int64_t)n * Ho * Wo * cv;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int c = (int)(t % cv);
@@ -303,7 +318,10 @@ __global__ __launch_bounds__(256) void relayout_kernel(const uint16_t* __restric
         int yy = r / Wo, xx = r - yy * Wo;
         if (out_pad) { --yy; --xx; }
         u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const u32x4_t*)(in + tok_row(img, yy * W + xx, H, W, in_pad) * C + c * 8);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int ys = up ? yy >> 1 : yy, xs = up ? xx >> 1 : xx;
+            v = *(const u32x4_t*)(in + tok_row(img, ys * Wi + xs, Hi, Wi, in_pad) * C + c * 8);
+        }
         ((u32x4_t*)out)[t] = v;
     }
 }
@@ -525,7 +543,8 @@ size_t sd_groupnorm_ws_floats(int n, int HW, int groups) {
 }
 
 // in_pad / out_pad: the input / output is in the padded layout (tok_row); the output's border rows are zeroed
-static int gn_slab_tokens(int HW) { int s = 256; while ((HW + s - 1) / s > 256) s *= 2; return s; }
+// tokens per statistics slab: small slabs = many workgroups (the pass is latency-bound on few), at most 1024 slabs per image
+static int gn_slab_tokens(int HW) { int s = 64; while ((HW + s - 1) / s > 1024) s *= 2; return s; }
 
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
                         int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
@@ -545,10 +564,11 @@ hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, cons
     return hipGetLastError();
 }
 
-hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, hipStream_t st) {
-    if (C % 8 != 0) return hipErrorInvalidValue;
+// H, W: the OUTPUT's extent (up: the input is (H / 2) x (W / 2))
+hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, int up, hipStream_t st) {
+    if (C % 8 != 0 || (up && ((H | W) & 1))) return hipErrorInvalidValue;
     const int64_t rows = out_pad ? (int64_t)n * (H + 2) * (W + 2) : (int64_t)n * H * W;
-    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, st, in, out, n, H, W, C, in_pad, out_pad);
+    hipLaunchKernelGGL(relayout_kernel, dim3(grid_for(rows * (C >> 3))), dim3(256), 0, st, in, out, n, H, W, C, in_pad, out_pad, up);
     return hipGetLastError();
 }
 

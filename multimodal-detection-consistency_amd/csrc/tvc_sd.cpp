@@ -142,6 +142,24 @@ struct Run {
         return y;
     }
     // 3x3 convolution, padding 1: stride 1 / 2, or on the nearest-2x upsampling of x
+    // Upsample2D: nearest-2x then a 3x3 convolution -- the upsampled tensor is written ONCE in the padded layout (4x the
+    // input's rows, not the 36x of im2col rows) and convolved as nine planes; the dense result is what the next block reads
+    Act upsample_conv(const Act& x, const std::string& prefix, int Cout) {
+        Act y = act(x.n, 2 * x.H, 2 * x.W, Cout);
+        const size_t mark = off;
+        Act xp = act_padded(x.n, 2 * x.H, 2 * x.W, x.C);
+        if (live()) {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)xp.rows() * x.C * 2.5);
+            hip(sd_relayout(x.p, xp.p, x.n, 2 * x.H, 2 * x.W, x.C, x.pad, 1, 1, st), "sd_relayout(up)");
+        }
+        Act yp = conv3x3_planes(xp, prefix, Cout);
+        if (live()) {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)y.tok() * Cout * 4.0);
+            hip(sd_relayout(yp.p, y.p, y.n, y.H, y.W, Cout, 1, 0, 0, st), "sd_relayout");
+        }
+        off = mark;
+        return y;
+    }
     Act conv3x3(const Act& x, const std::string& prefix, int Cout, int stride = 1, int up = 0) {
         const int Hs = up ? 2 * x.H : x.H, Ws = up ? 2 * x.W : x.W;
         const int Ho = (Hs - 1) / stride + 1, Wo = (Ws - 1) / stride + 1;
@@ -365,7 +383,7 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
             x = R.resnet(cat, pi + ".resnets." + std::to_string(j) + ".", c, tadd, eps);
             if (attn) x = R.transformer(x, pi + ".attentions." + std::to_string(j) + ".", ctx16);
         }
-        if (i != nb - 1) x = R.conv3x3(x, pi + ".upsamplers.0.conv.", c, 1, 1);
+        if (i != nb - 1) x = R.upsample_conv(x, pi + ".upsamplers.0.conv.", c);
     }
     Act y = R.groupnorm(x, "conv_norm_out.", eps, 1, nullptr, 0, true);
     {
@@ -402,7 +420,7 @@ void vae_forward(Run& R, const float* latents, int n, int H, int W, float* image
         const int c = d.vae_block_out_channels[nb - 1 - i];
         const std::string pi = "decoder.up_blocks." + std::to_string(i);
         for (int j = 0; j < d.vae_layers_per_block + 1; ++j) x = R.resnet(x, pi + ".resnets." + std::to_string(j) + ".", c, nullptr, eps);
-        if (i != nb - 1) x = R.conv3x3(x, pi + ".upsamplers.0.conv.", c, 1, 1);
+        if (i != nb - 1) x = R.upsample_conv(x, pi + ".upsamplers.0.conv.", c);
     }
     Act y = R.groupnorm(x, "decoder.conv_norm_out.", eps, 1, nullptr, 0, true);
     float* o = nullptr;
@@ -672,12 +690,12 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
         } else if (kind == 3) {
             // stride 1: the 9-plane GEMM on the padded layout (dense -> padded with zero borders -> conv -> dense)
             Act xp = R.act_padded(n, H, W, Cin);
-            if (R.live()) R.hip(sd_relayout(x.p, xp.p, n, H, W, Cin, 0, 1, R.st), "relayout");
+            if (R.live()) R.hip(sd_relayout(x.p, xp.p, n, H, W, Cin, 0, 1, 0, R.st), "relayout");
             Act yp = R.conv3x3_planes(xp, p, Cout);
             y = R.act(n, H, W, Cout);
-            if (R.live()) R.hip(sd_relayout(yp.p, y.p, n, H, W, Cout, 1, 0, R.st), "relayout");
+            if (R.live()) R.hip(sd_relayout(yp.p, y.p, n, H, W, Cout, 1, 0, 0, R.st), "relayout");
         } else {
-            y = R.conv3x3(x, p, Cout, kind == 4 ? 2 : 1, kind == 5 ? 1 : 0);
+            y = kind == 5 ? R.upsample_conv(x, p, Cout) : R.conv3x3(x, p, Cout, 2, 0);
         }
         if (R.live()) R.hip(sd_tokens_bf16_to_nchw(y.p, out_dev, y.n, y.C, y.H * y.W, R.st), "tokens_to_nchw");
     });

@@ -72,6 +72,9 @@ def parse(argv=None):
     p.add_argument("--unplanted-bank", action="store_true",
                    help="pure Gaussian bank (no row reaches the 0.3 threshold, the reference branch of the consistency "
                         "kernel sees no references); default: neighbours of the text rows are planted")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="do not measure roofline.traffic live (two rocprofv3 --pmc child passes of this command with --steps 1, "
+                        "run BEFORE this process touches the GPU; the default N=1 run does, ~1.5 min); fall back to the committed profile")
     p.add_argument("--master-port", type=int, default=0)
     p.add_argument("--dry-run-launch", action="store_true",
                    help="launch-contract rehearsal WITHOUT a GPU (CPU test of the --gpus N launcher): the ranks form a "
@@ -118,6 +121,48 @@ def launch_ranks(a) -> int:
     sys.stdout.write(line)
     sys.stdout.flush()
     return rc
+
+
+# --------------------------------------------------------------------------- live HBM traffic (PMC)
+def measure_traffic_live(a):
+    """roofline.traffic measured IN THIS RUN: two child processes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py
+    --steps 1 ...` (separate passes, counters only, the program itself after `--`), started before this process touches
+    the GPU.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM): KB counters; on gfx950 FETCH_SIZE tallies the
+    128-byte requests of wide reads at 64 B (x2; calibrated on a launch of known bytes: profiles/r03_pmc_calibration.json),
+    WRITE_SIZE exact.  Returns {kernel: {launches, hbm_MB_per_launch}} or None (no rocprofv3 / a pass failed)."""
+    import collections, csv, glob, re, shutil, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="tvc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    base = [sys.executable, str(Path(__file__).resolve()), "--steps", "1", "--warmup", "1", "--serial-towers", "--no-cpu-baseline",
+            "--no-extras", "--no-profile-pass", "--no-live-traffic", "--model", a.model, "--batch", str(a.batch),
+            "--variants", str(a.variants), "--bank-rows", str(a.bank_rows)]
+    per = {}
+    try:
+        for counter, tag in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+            cmd = [exe, "--pmc", counter, "-d", os.path.join(tmp, tag), "-o", tag, "--output-format", "csv", "--"] + base
+            r = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
+            files = glob.glob(os.path.join(tmp, tag, "**", f"{tag}_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
+                tot[name] += float(row["Counter_Value"]); disp[name].add(row["Dispatch_Id"])
+            per[tag] = {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, (fkb, n) in per["f"].items():
+        if k in per["w"] and not k.startswith("at::") and "rocclr" not in k:
+            out[k] = {"launches": n, "hbm_MB_per_launch": round((2 * fkb + per["w"][k][0]) / 1024, 1)}
+    return out
 
 
 def host_cpus() -> int:
@@ -204,6 +249,15 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
+
+    # PMC passes run as child processes BEFORE anything here touches the GPU (default N=1 run of the default workload only)
+    live_traffic = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_live_traffic and not a.no_extras and not a.no_profile_pass
+            and not a.shard_bank and not a.dry_run_launch):
+        t_pm = time.perf_counter()
+        live_traffic = measure_traffic_live(a)
+        if live_traffic is not None:
+            live_traffic["_seconds"] = round(time.perf_counter() - t_pm, 1)
 
     import torch
     import torch.distributed as dist
@@ -416,7 +470,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": wl,
-                       "global_batch": world * B, "parallelism": (f"dp{world} queries x bank rows sharded {world}-way (RCCL all-gather + all-to-all of partial top-k)"
+                       "global_batch": world * B, "parallelism": (f"dp{world} queries x bank rows sharded {world}-way (RCCL all-gather + all-to-all of partial top-k; exchange={a.exchange}"
+                                                       + (", pipelined under the next batch's towers" if a.exchange == "fused" and not a.serial_towers else "") + ")"
                                        if a.shard_bank else f"dp{world}"),
                        "text_packing": "dense-77" if a.dense_text else ("eot-packed" + ("" if a.no_prefix_sharing else " + variant prefix sharing") + " (bit-identical, see DESIGN.md)"),
                        "bank": "gaussian" if a.unplanted_bank else "gaussian + planted neighbours of the text rows",

@@ -146,6 +146,7 @@ def measure_traffic_live(a):
             r = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
             files = glob.glob(os.path.join(tmp, tag, "**", f"{tag}_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
+                print(f"bench.py: live traffic pass {counter} failed (rc {r.returncode}, files {files}); using the committed profile", file=sys.stderr)
                 return None
             tot, disp = collections.defaultdict(float), collections.defaultdict(set)
             for row in csv.DictReader(open(files[0])):
@@ -154,7 +155,8 @@ def measure_traffic_live(a):
                 name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
                 tot[name] += float(row["Counter_Value"]); disp[name].add(row["Dispatch_Id"])
             per[tag] = {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
-    except Exception:
+    except Exception as ex:
+        print(f"bench.py: live traffic measurement failed ({type(ex).__name__}: {ex}); using the committed profile", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -428,9 +430,19 @@ def main():
                 "traffic": None, "launches_per_step": g["launches"],
                 "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
 
-    if roof is not None and rank == 0:
-        # HBM bytes per launch of the dominant kernel family: NOT measured by this run (bench.py cannot collect
-        # PMC counters); a static figure from the committed rocprofv3 --pmc summary of this same command
+    if roof is not None and rank == 0 and live_traffic:
+        ring = [(v["launches"], v["hbm_MB_per_launch"]) for kk, v in live_traffic.items() if kk.startswith("gemm_ring")]
+        if ring:
+            roof["traffic"] = round(sum(n * mb for n, mb in ring) / sum(n for n, _ in ring) / 1e3, 3)
+            roof["traffic_unit"] = "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, launch-weighted mean over the ring GEMMs)"
+            roof["traffic_source"] = (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only) of this command with "
+                                      f"--steps 1, run by bench.py as child processes before the timed run ({live_traffic.get('_seconds')} s)")
+            roof["traffic_by_kernel_GB"] = {kk: round(v["hbm_MB_per_launch"] / 1e3, 3) for kk, v in live_traffic.items()
+                                            if isinstance(v, dict) and (kk.startswith("gemm_ring") or kk.startswith("layernorm") or
+                                                                        kk.startswith("attention_kernel<17") or kk.startswith("bank_filter"))}
+    if roof is not None and rank == 0 and roof.get("traffic") is None:
+        # HBM bytes per launch of the dominant kernel family when the live PMC passes did not run (--no-live-traffic, no
+        # rocprofv3): a static figure from the committed rocprofv3 --pmc summary of this same command
         try:
             import glob
             here = os.path.dirname(os.path.abspath(__file__))

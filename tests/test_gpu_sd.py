@@ -230,3 +230,32 @@ def test_config4_smoke_sd_reference_generator_feeds_the_detector(pkg):
     assert "generative_consistency" in out["details"]["consistency_scores"]
     assert np.isfinite(out["consistency_score"])
     clip.engine.close()
+
+
+def test_unet_and_vae_shapes_and_batch_split_invariance(pkg, sd):
+    """Non-square latents, a single sample, and the VAE's image chunking (6 images of 512 x 512 are decoded in two chunks):
+    every sample's result is independent of its batch mates (no cross-sample arithmetic anywhere: statistics are per image)."""
+    arch, uw, vw, k = sd
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn((1, 4, 16, 24), generator=g)
+    ctx = torch.randn((1, arch.ctx, arch.cross_attention_dim), generator=g)
+    got = k.unet(lat, 500.0, ctx)
+    with torch.no_grad():
+        ref = sd_oracle.unet_forward(uw, arch, lat, 500, ctx)
+    r2, _ = rel(got, ref)
+    print(f"[measured] UNet forward, 1 sample of 16 x 24 latents: rel L2 {r2:.2e}")
+    assert got.shape == (1, 4, 16, 24) and r2 < 2.5e-2
+    # the same sample inside a batch of 3 (the other samples differ)
+    lat3 = torch.cat([torch.randn((1, 4, 16, 24), generator=g), lat, torch.randn((1, 4, 16, 24), generator=g)])
+    ctx3 = torch.cat([torch.randn((1, arch.ctx, arch.cross_attention_dim), generator=g), ctx, ctx])
+    got3 = k.unet(lat3, 500.0, ctx3)
+    assert (got3[1:2] - got).abs().max().item() < 2e-2 * got.abs().max().item()      # same arithmetic up to GEMM tile placement
+    # VAE: 6 images of 64 x 64 latents -> chunks of 5 + 1; each equals its own single-image decode bit for bit or to bf16 noise
+    z = torch.randn((6, 4, 64, 64), generator=g)
+    imgs = k.vae_decode(z)
+    assert imgs.shape == (6, 3, 512, 512) and torch.isfinite(imgs).all()
+    for i in (0, 4, 5):
+        one = k.vae_decode(z[i:i + 1])
+        assert (imgs[i:i + 1] - one).abs().max().item() < 2e-2
+    with pytest.raises(pkg.TVCError):
+        k.unet(torch.zeros((1, 4, 12, 12)), 1.0, ctx)          # H, W must be multiples of 8 (three stride-2 levels)

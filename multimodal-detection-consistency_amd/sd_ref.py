@@ -161,9 +161,15 @@ class SDReferenceGenerator:
     def __init__(self, config: Optional[SDReferenceConfig] = None, sd_model=None, text_augmenter=None, clip_model=None):
         self.config = config or SDReferenceConfig()
         if sd_model is None:
-            from .sd_model import SDModelConfig, StableDiffusionModel
-            sd_model = StableDiffusionModel(SDModelConfig(model_name=self.config.sd_model, device=self.config.device),
-                                            clip_model=clip_model)
+            # src/sd_ref.py:291-317 builds its StableDiffusionModel here and, when that fails, logs and goes on without one
+            # (every generation call then reports an error instead of raising) -- mirrored
+            try:
+                from .sd_model import SDModelConfig, StableDiffusionModel
+                sd_model = StableDiffusionModel(SDModelConfig(model_name=self.config.sd_model, device=self.config.device),
+                                                clip_model=clip_model)
+            except Exception as e:                                 # noqa: BLE001
+                logger.error("could not build the latent-diffusion model: %s", e)
+                sd_model = None
         elif isinstance(sd_model, str) and sd_model == "none":
             sd_model = None
         self.sd_model = sd_model
@@ -179,7 +185,7 @@ class SDReferenceGenerator:
         c = self.config
         try:
             if self.sd_model is None:
-                raise RuntimeError("this generator was built without a latent-diffusion model (sd_model='none')")
+                raise RuntimeError("this generator has no latent-diffusion model (sd_model='none', or building it failed: no GPU?)")
             num_images = num_images or c.num_images_per_prompt
             use_variants = use_variants if use_variants is not None else c.use_text_variants
             key = self._get_cache_key(prompt, num_images, use_variants, seeds)

@@ -143,7 +143,7 @@ def measure_traffic_live(a):
     try:
         for counter, tag in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
             cmd = [exe, "--pmc", counter, "-d", os.path.join(tmp, tag), "-o", tag, "--output-format", "csv", "--"] + base
-            r = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
+            r = subprocess.run(cmd, env=env, cwd=str(ROOT), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
             files = glob.glob(os.path.join(tmp, tag, "**", f"{tag}_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 print(f"bench.py: live traffic pass {counter} failed (rc {r.returncode}, files {files}); using the committed profile", file=sys.stderr)

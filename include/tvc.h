@@ -16,7 +16,11 @@
  *   - return value 0 = TVC_OK, otherwise an error code; the message is
  *     available from tvc_last_error();
  *   - a handle belongs to one GPU and is not thread-safe (the Python shim
- *     holds a lock around submission);
+ *     holds a lock around submission); entry points that share an internal
+ *     workspace (two calls into the same tower, any two tvc_sd_* calls, two
+ *     bank searches) must be issued on ONE stream or be ordered by the caller
+ *     -- the vision tower, the text tower and the bank search each have their
+ *     own workspace and may run on three streams side by side;
  *   - bf16 buffers are raw uint16_t bit patterns (round-to-nearest-even).
  */
 #ifndef TVC_H_

@@ -15,6 +15,7 @@
 //
 // "Swapped" products keep the query on the lane (column) dimension, so row
 // statistics are per-lane scalars and the output is 8-byte row pieces.
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include <mutex>
@@ -68,7 +69,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     // branches, not exec masks
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int item_local = wave / WPS, wsub = wave - item_local * WPS;
-    int item = blockIdx.x * IPW + item_local;
+    // XCD-contiguous item order: consecutive workgroup ids alternate over the 8 XCDs, so with item = blockIdx the 16 heads
+    // of a sequence -- 16 adjacent 128-byte pieces of every packed row -- were fetched by 8 different L2s at unrelated
+    // times.  With a contiguous item range per XCD the heads of a sequence run on neighbouring CUs of ONE XCD at the same
+    // time and every 2 KiB row is fetched whole within a short window: 337 -> 310 us per ViT-L/14 layer call.
+    int item = xcd_contiguous(blockIdx.x, gridDim.x) * IPW + item_local;
     const bool active = item < n_items;
     if (!active) item = n_items - 1;
     const int seq = item / heads, h = item - seq * heads;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     if (T > MAXT * 16) T = MAXT * 16;      // host guarantees this; never index past the region
     const int NT = EXACT ? MAXT : (T + 15) >> 4;          // key tiles of 16
     const int NP = (NT + 1) >> 1;          // key pairs of 32
-    const int KT = NT * 16, VT = NP * 32;
+    const int KT = NT * 16, VT = EXACT ? NT * 16 : NP * 32;   // EXACT: an unpaired last tile multiplies its own V rows by zeros
     char* ldsK = smem + item_local * region_bytes;
     char* ldsV = ldsK + k_bytes;
     const int64_t ld = 3 * (int64_t)width;
@@ -129,8 +134,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     if (wsub < NQ) { const uint16_t* qp = q_ptr(wsub); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
 
     // ---- fill K / V images (zero beyond T).  ALL global loads of the item -- both images and the first query block --
-    // are issued before the first LDS write, so the workgroup pays ONE memory latency per item (K and V used to be
-    // filled one after the other: two).
+    // are issued before the first LDS write, so the workgroup pays ONE memory latency per item.  The loads are
+    // UNCONDITIONAL (row index clamped, zeros selected at the LDS write): behind a per-lane `if (key < T)` every load was
+    // its own basic block and hipcc put an `s_waitcnt vmcnt(0)` between the K loads and the V loads -- two latencies in
+    // series, 11.7 k of the 40 k clocks of a workgroup's life (in-kernel stamps, round 3).
     constexpr int STEP = WPS * 64;
     constexpr int KIT = (MAXT * 16 * 8 + STEP - 1) / STEP;
     constexpr int VIT = (((MAXT + 1) / 2) * 32 * 8 + STEP - 1) / STEP;
@@ -140,32 +147,43 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         for (int i = 0; i < KIT; ++i) {
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
-            kv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) kv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + width + h * ATT_DH + c * 8));
+            kv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key < T ? key : T - 1) * ld + width + h * ATT_DH + c * 8));
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
-            vv[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (key < T) vv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key) * ld + 2 * width + h * ATT_DH + c * 8));
+            vv[i] = ATT_LD_KV((const u32x4_t*)(qkv + key_row(key < T ? key : T - 1) * ld + 2 * width + h * ATT_DH + c * 8));
         }
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
-            if (idx < KT * 8) *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = kv[i];
+            if (idx < KT * 8) *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = key < T ? kv[i] : u32x4_t{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int idx = tsub + i * STEP;
             const int key = idx >> 3, c = idx & 7;
-            if (idx < VT * 8) *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = vv[i];
+            if (idx < VT * 8) *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = key < T ? vv[i] : u32x4_t{0u, 0u, 0u, 0u};
         }
     }
     __syncthreads();
     if (!active) return;
 
+    // EXACT: the K fragments of a lane do not depend on the query block.  The first KPIN key tiles' fragments stay in
+    // registers for the whole item (120 VGPRs at 15 tiles); the last two tiles of the 17 are read per block through a
+    // pointer the compiler cannot prove loop-invariant -- with all 17 pinned (what hipcc's own hoisting did) the block
+    // below needs 262 registers once its running max is the three-operand form, and spills.
+    constexpr int KPIN = EXACT ? (MAXT > 15 ? 15 : MAXT) : 0;
+    bf16x8_t ka[KPIN > 0 ? KPIN : 1], kb[KPIN > 0 ? KPIN : 1];
+    if (EXACT) {
+#pragma unroll
+        for (int t = 0; t < KPIN; ++t) {
+            ka[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw0);
+            kb[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw1);
+        }
+    }
     for (int qb = wsub; qb < NQ; qb += WPS) {
         const int qr = qb * 16 + r16;
         const bf16x8_t bq0 = nq0, bq1 = nq1;
@@ -178,6 +196,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
         const int nt_c = (qmax >> 4) + 1;
         const int nt_q = EXACT ? MAXT : (CAUSAL ? (nt_c < NT ? nt_c : NT) : NT);
 
+        int zoff = 0;
+        asm volatile("" : "+v"(zoff));          // opaque 0: keeps the un-pinned K reads inside the loop
+        const char* ldsK_i = ldsK + zoff;
         f32x4_t s[MAXT];
         float mx = -INFINITY;          // max of the RAW scores (scaling by a positive constant is monotonic)
         if (EXACT) {
@@ -186,21 +207,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const f32x4_t c0 = (t == MAXT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                const bf16x8_t a0 = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw0);
+                const bf16x8_t a0 = t < KPIN ? ka[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw0);
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, c0, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                const bf16x8_t a1 = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw1);
+                const bf16x8_t a1 = t < KPIN ? kb[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw1);
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
             }
+            // IEEE-754-2019 maximum (NaN-propagating): hipcc emits v_maximum3_f32 with no canonicalising copy of the
+            // MFMA outputs -- 54 max instructions per block where fmaxf costs 121.  A NaN score makes the query's
+            // output NaN either way.
             float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                m0 = fmaxf(m0, fmaxf(s[t][0], s[t][1]));
-                m1 = fmaxf(m1, fmaxf(s[t][2], s[t][3]));
+                m0 = __builtin_elementwise_maximum(m0, __builtin_elementwise_maximum(s[t][0], s[t][1]));
+                m1 = __builtin_elementwise_maximum(m1, __builtin_elementwise_maximum(s[t][2], s[t][3]));
             }
-            mx = fmaxf(m0, m1);
+            mx = __builtin_elementwise_maximum(m0, m1);
         } else {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                     const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                         (__attribute__((address_space(3))) bf16x4_t*)(vb + t0 * 16 * ATT_VROW));
                     const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vb + t1 * 16 * ATT_VROW));
+                        (__attribute__((address_space(3))) bf16x4_t*)(vb + ((EXACT && t1 >= MAXT) ? t0 : t1) * 16 * ATT_VROW));
                     bf16x8_t a;
                     a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3];
                     a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
@@ -271,17 +295,30 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
                 osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, osum, 0, 0, 0);
             }
         }
+        // The NEXT block's query fragments are waited for HERE, before this block's stores are issued: vmcnt counts
+        // stores too, and the stores sit in a per-lane conditional, so a wait for the (older) Q loads at the loop's
+        // back-edge was an `s_waitcnt vmcnt(0)` that also waited out the four stores just issued -- 1 500 of the 5 000
+        // clocks of a query block (in-kernel stamps, round 3).  Now nobody waits for the stores until the next block's
+        // products are done.
+        asm volatile("" : "+v"(nq0), "+v"(nq1));
         const float lsum = osum[0];          // every row of the ones tile holds the column (= query) sum
-        if (pool_mode ? (r16 == 0) : (qr < own)) {
-            const float inv = 1.0f / lsum;
-            uint16_t* op = out + (pool_mode ? (int64_t)seq : row0 + qr) * (int64_t)width + h * ATT_DH + 4 * g;
+        // A lane's 4 features per 16-wide tile are 8 B; swapping 16-lane rows between the tiles md and md + 1
+        // (v_permlane16_swap, as the GEMM's bf16 epilogue does) leaves every lane with 8 consecutive features: two 16-byte
+        // stores per lane and 64 contiguous bytes per query row and instruction, instead of four 8-byte stores that
+        // scatter 32-byte pieces.  The partner lanes carry the same query column, so the swap sits outside the mask.
+        const float inv = 1.0f / lsum;
+        u32x4_t ow[2];
 #pragma unroll
-            for (int md = 0; md < 4; ++md) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(o[md][0] * inv, o[md][1] * inv);
-                w[1] = pack_bf16x2(o[md][2] * inv, o[md][3] * inv);
-                ATT_ST_O((u32x2_t*)(op + md * 16), w);
-            }
+        for (int mp = 0; mp < 2; ++mp) {
+            const f32x4_t v0 = o[2 * mp] * inv, v1 = o[2 * mp + 1] * inv;
+            const auto r0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+            ow[mp][0] = r0[0]; ow[mp][1] = r1[0]; ow[mp][2] = r0[1]; ow[mp][3] = r1[1];
+        }
+        if (pool_mode ? (r16 == 0) : (qr < own)) {
+            uint16_t* op = out + (pool_mode ? (int64_t)seq : row0 + qr) * (int64_t)width + h * ATT_DH + (g & 1) * 16 + (g >> 1) * 8;
+            ATT_ST_O((u32x4_t*)op, ow[0]);
+            ATT_ST_O((u32x4_t*)(op + 32), ow[1]);
         }
     }
 }
@@ -292,7 +329,9 @@ static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* 
                              int pool_mode = 0, const int32_t* pool_row = nullptr) {
     const int NT = (max_T + 15) / 16, NP = (NT + 1) / 2;
     const int k_bytes = NT * 16 * ATT_KROW;
-    const int region = k_bytes + NP * 32 * ATT_VROW;
+    // EXACT: V rows of whole tiles only (an unpaired last tile needs no zero partner rows).  257 tokens: 34 816 + 43 520 =
+    // 78 336 B, two workgroups per CU.
+    const int region = k_bytes + (EXACT ? NT * 16 : NP * 32) * ATT_VROW;
     constexpr int IPW = NW / WPS;
     const size_t lds = (size_t)region * IPW;
     static std::once_flag attr_once;          // per instantiation; thread-safe

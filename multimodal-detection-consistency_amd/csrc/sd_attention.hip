@@ -24,6 +24,8 @@
 
 namespace {
 
+__device__ __forceinline__ float mx3(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+
 template <int DH, int QB, int NW>
 struct FaCfg {
     static constexpr int KS = (DH + 31) / 32;           // 32-wide k-steps of Q.K^T
@@ -42,10 +44,16 @@ struct FaCfg {
     static constexpr int PIECES = 64 * DCH;             // 16-byte pieces of one operand tile
     static constexpr int NT = NW * 64;                  // threads per workgroup
     static constexpr int NIT = (PIECES + NT - 1) / NT;  // staging pieces per thread and operand
+    // TWO eight-wave workgroups per CU (128 registers per lane) where the kernel fits them: head dims <= 48 with ONE staging
+    // register set (the other workgroup's arithmetic hides a tile's load latency instead of a second set).  Two resident
+    // workgroups run out of phase, so one's softmax overlaps the other's products: head_dim 40 at T = 4096 1 099 -> 928 us
+    // (head_dim 32: 1 052 -> 876).  Head dims 56 / 64 fit with one spilled register and run the same as before; 80 needs 174.
+    static constexpr bool OCC2 = NW == 8 && DH <= 48;
+    static constexpr int NSETS = OCC2 ? 1 : 2;
 };
 
 template <int DH, int QB, int NW>
-__global__ __launch_bounds__(NW * 64) void sd_flash_attention_kernel(const uint16_t* __restrict__ Q, int64_t ldq,
+__global__ __launch_bounds__(NW * 64, (NW == 8 && DH <= 48) ? 4 : 1)    /* = FaCfg::OCC2 */ void sd_flash_attention_kernel(const uint16_t* __restrict__ Q, int64_t ldq,
                                                                  const uint16_t* __restrict__ K, int64_t ldk,
                                                                  const uint16_t* __restrict__ V, int64_t ldv,
                                                                  uint16_t* __restrict__ O, int64_t ldo, int Tq, int Tk,
@@ -102,33 +110,34 @@ __global__ __launch_bounds__(NW * 64) void sd_flash_attention_kernel(const uint1
     const uint16_t* vp[C::NIT];
 #pragma unroll
     for (int i = 0; i < C::NIT; ++i) {
-        const int idx = tid + i * NT;
+        int idx = tid + i * NT;
+        if (idx >= C::PIECES) idx = C::NIT > 1 ? tid : tid % C::PIECES;      // no last piece: re-read a valid one (never written to LDS)
         prow[i] = idx / C::DCH;
         pcol[i] = idx - prow[i] * C::DCH;
         kp[i] = kbase + (int64_t)prow[i] * ldk + pcol[i] * 8;
         vp[i] = vbase + (int64_t)prow[i] * ldv + pcol[i] * 8;
     }
     const bool last_piece_valid = (tid + (C::NIT - 1) * NT) < C::PIECES;      // only the last piece of a thread can be out of range
-    // TWO register sets: tile t + 2 is requested while tile t is multiplied
+    // TWO register sets: tile t + 2 is requested while tile t is multiplied.
+    // Every load below is UNCONDITIONAL (a thread without a last piece re-reads piece 0 of its column; the tile index is
+    // clamped by the caller; only the LDS write is masked): vmcnt is a counter, and with the loads behind per-thread or
+    // per-tile conditionals hipcc could not count the other register set's loads -- the wait before a tile's LDS write
+    // was `vmcnt(0)`, which drained the set requested one tile ago as well and made the prefetch one tile deep.
     u32x4_t kregA[C::NIT], vregA[C::NIT], kregB[C::NIT], vregB[C::NIT];
     auto prefetch = [&](int key0, u32x4_t (&kreg)[C::NIT], u32x4_t (&vreg)[C::NIT]) __attribute__((always_inline)) {
         if (key0 + 64 <= Tk) {                 // full tile (uniform): unguarded loads through the per-thread pointers
 #pragma unroll
             for (int i = 0; i < C::NIT; ++i) {
-                if (i < C::NIT - 1 || last_piece_valid) {
-                    kreg[i] = *(const u32x4_t*)(kp[i] + (int64_t)key0 * ldk);
-                    vreg[i] = *(const u32x4_t*)(vp[i] + (int64_t)key0 * ldv);
-                }
+                kreg[i] = *(const u32x4_t*)(kp[i] + (int64_t)key0 * ldk);
+                vreg[i] = *(const u32x4_t*)(vp[i] + (int64_t)key0 * ldv);
             }
         } else {                               // ragged last tile: rows clamped to the last key (their scores start at -inf)
 #pragma unroll
             for (int i = 0; i < C::NIT; ++i) {
-                if (i < C::NIT - 1 || last_piece_valid) {
-                    int r = key0 + prow[i];
-                    r = r < Tk ? r : Tk - 1;
-                    kreg[i] = *(const u32x4_t*)(kbase + (int64_t)r * ldk + pcol[i] * 8);
-                    vreg[i] = *(const u32x4_t*)(vbase + (int64_t)r * ldv + pcol[i] * 8);
-                }
+                int r = key0 + prow[i];
+                r = r < Tk ? r : Tk - 1;
+                kreg[i] = *(const u32x4_t*)(kbase + (int64_t)r * ldk + pcol[i] * 8);
+                vreg[i] = *(const u32x4_t*)(vbase + (int64_t)r * ldv + pcol[i] * 8);
             }
         }
     };
@@ -157,12 +166,12 @@ __global__ __launch_bounds__(NW * 64) void sd_flash_attention_kernel(const uint1
 
     const int nkt = (Tk + 63) >> 6;
     prefetch(0, kregA, vregA);
-    if (nkt > 1) prefetch(64, kregB, vregB);
+    if (C::NSETS == 2) prefetch(nkt > 1 ? 64 : 0, kregB, vregB);
     auto tile = [&](int kt, u32x4_t (&kreg)[C::NIT], u32x4_t (&vreg)[C::NIT]) __attribute__((always_inline)) {
         __syncthreads();                       // every wave is done reading the previous tile (and the pad columns are zero)
         commit(kreg, vreg);
         __syncthreads();
-        if (kt + 2 < nkt) prefetch((kt + 2) * 64, kreg, vreg);      // in flight behind two tiles' arithmetic
+        prefetch((kt + C::NSETS < nkt ? kt + C::NSETS : nkt - 1) * 64, kreg, vreg);      // in flight behind NSETS tiles' arithmetic (past the end: the last tile again, never used)
         const int key0 = kt * 64;
         const bool ragged = key0 + 64 > Tk;   // uniform; true for the last tile only
         // ---- S^T = K . Q^T for the 4 key sub-tiles of 16; the K fragment of a (sub-tile, k-step) feeds all QB blocks
@@ -187,9 +196,10 @@ __global__ __launch_bounds__(NW * 64) void sd_flash_attention_kernel(const uint1
         bf16x8_t pb[QB][2];
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
-            float mx = fmaxf(fmaxf(s[u][0][0], s[u][0][1]), fmaxf(s[u][0][2], s[u][0][3]));
+            // IEEE-754-2019 maximum (v_maximum3_f32, NaN-propagating: no canonicalising copies of the MFMA outputs)
+            float mx = mx3(mx3(s[u][0][0], s[u][0][1]), mx3(s[u][0][2], s[u][0][3]));
 #pragma unroll
-            for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[u][t][0], s[u][t][1]), fmaxf(s[u][t][2], s[u][t][3])));
+            for (int t = 1; t < 4; ++t) mx = mx3(mx, mx3(mx3(s[u][t][0], s[u][t][1]), mx3(s[u][t][2], s[u][t][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[u], mx);          // finite: every tile holds at least one key < Tk
@@ -234,9 +244,13 @@ __global__ __launch_bounds__(NW * 64) void sd_flash_attention_kernel(const uint1
             }
         }
     };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        tile(kt, kregA, vregA);
-        if (kt + 1 < nkt) tile(kt + 1, kregB, vregB);
+    if (C::NSETS == 1) {
+        for (int kt = 0; kt < nkt; ++kt) tile(kt, kregA, vregA);
+    } else {
+        for (int kt = 0; kt < nkt; kt += 2) {
+            tile(kt, kregA, vregA);
+            if (kt + 1 < nkt) tile(kt + 1, kregB, vregB);
+        }
     }
     // ---- the lane groups hold disjoint keys of the same query: combine the row sums, normalise, store
 #pragma unroll

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_dq_kernel(const uint16_t
     const int width = heads * ATT_DH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+    // XCD-contiguous item order, as the forward kernel: the 16 heads of a sequence -- adjacent 128-byte pieces of every
+    // packed row -- run on neighbouring CUs of one XCD at the same time (attention.hip)
+    const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int seq = item / heads, h = item - seq * heads;
     const int64_t row0 = (int64_t)seq * T, ld = 3 * (int64_t)width;
     const int NT = (T + 15) >> 4, NP = (NT + 1) >> 1;
     char* ldsK = smem;                                   // [NP*32][160]: row reads (S) and transposed reads (dQ)
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_dkv_kernel(const uint16_
     const int width = heads * ATT_DH;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+    // XCD-contiguous item order, as the forward kernel: the 16 heads of a sequence -- adjacent 128-byte pieces of every
+    // packed row -- run on neighbouring CUs of one XCD at the same time (attention.hip)
+    const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int seq = item / heads, h = item - seq * heads;
     const int64_t row0 = (int64_t)seq * T, ld = 3 * (int64_t)width;
     const int NT = (T + 15) >> 4, NP = (NT + 1) >> 1;
     char* ldsQ = smem;                                   // [NP*32][160] queries: row reads (S) + transposed reads (dK)

@@ -70,12 +70,12 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         {
             // D1 still points at the PREVIOUS layer's out-projection output here
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * (pending ? 14.0 : 6.0));
+            // gradient mode keeps the residual stream as layer l sees it (X + the pending deltas): ln_1 writes it to the
+            // kept buffer while it normalises (`xsum_out`) -- no separate device-to-device copy of X per layer
             HIP_TRY(launch_layernorm(X, d, nullptr, pending ? D1 : nullptr, 1, w.ln1_g, w.ln1_b, H, rows, d, st,
-                                     pending ? D2 : nullptr));
+                                     pending ? D2 : nullptr, 0, gs ? gs->x + (size_t)l * rows * d : nullptr));
         }
         if (gs) {
-            // the residual stream as layer l sees it (X now holds it: ln_1 folded the pending deltas)
-            HIP_TRY(hipMemcpyAsync(gs->x + (size_t)l * rows * d, X, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, st));
             QKV = gs->qkv + (size_t)l * rows * 3 * d;
             D1 = gs->d1 + (size_t)l * rows * d;
         }

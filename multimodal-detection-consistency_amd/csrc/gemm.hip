@@ -532,13 +532,21 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     // (the ring's deep LDS-DMA pipeline also beats the one-tile kernel's wait-per-K-tile loop on launches of fewer
     // tiles than CUs, one tile per workgroup: TVC_GEMM_RING_MIN_TILES, default 64)
     static const int ring_min = [] { const char* v = getenv("TVC_GEMM_RING_MIN_TILES"); return v ? atoi(v) : 64; }();
-    const bool ring = deep && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= ring_min));
+    // Launches that opted into split-K (`splitk_small`: the latent-diffusion model, whose results carry no batch-position
+    // invariance to protect) and have 64..128 tiles of a DEEP K (a 3 x 3 convolution at 16 x 16 latents: 120 tiles x 180
+    // K-tiles) also take the split-K kernels below instead of one tile per workgroup on half the chip.
+    const int nk64_all = (int)((int64_t)L.K * L.planes / GEMM_BK);
+    const bool mid_split = L.splitk_small && L.splitk_ws && forced < 0 && ntiles >= ring_min && ntiles <= 128 && nk64_all >= 32 &&
+                           (size_t)ntiles * (256 / ntiles) * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes;
+    const bool ring = deep && !mid_split && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= ring_min));
     if (ring) {
         // ---- split-K tail: whole rounds to the ring kernel, the left-over tile columns split over K
         // Opt-in (TVC_GEMM_SPLITK_TAIL=1): it shortens the GEMM launches themselves by 1.4 % (89.7 vs 91.0 ms
         // per step) but the step does not get faster when the two towers run on two streams - the other
         // tower's kernels already fill the idle CUs of a last round - and it adds two launches per GEMM.
         static const bool tail_on = [] { const char* v = getenv("TVC_GEMM_SPLITK_TAIL"); return v && atoi(v) != 0; }();
+        // (`splitk_small` launches take it too, with whole tile COLUMNS for the ring kernel even when the tile rows do not
+        // divide 256: 96 token columns x 3 feature rows = 288 tiles -> 85 columns = 255 tiles in one round + 33 tiles split 7-way)
         const int full_tiles = ntiles / 256 * 256;
         const int jt_full = full_tiles / nIt;                 // tile columns the ring kernel keeps
         const int left = ntiles - jt_full * nIt;              // tiles of the left-over columns
@@ -546,8 +554,9 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         int S = left > 0 ? 256 / left : 0;
         if (S > nk64 / 4) S = nk64 / 4;
         if (S > 16) S = 16;
-        const bool tail = tail_on && forced < 0 && L.splitk_ws && jt_full >= 1 && left >= 1 && left <= 64 && S >= 2 &&
-                          (jt_full * nIt) % 256 + left > 0 && (jt_full * nIt) % 256 == 0 &&
+        const bool whole_rounds = (jt_full * nIt) % 256 == 0;
+        const bool tail = forced < 0 && L.splitk_ws && jt_full >= 1 && left >= 1 && S >= 2 &&
+                          ((tail_on && whole_rounds && left <= 64) || (L.splitk_small && left <= 128)) &&
                           (size_t)left * S * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes;
         if (tail) {
             GemmLaunch M2 = L;

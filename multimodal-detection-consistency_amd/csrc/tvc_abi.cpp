@@ -82,6 +82,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         GemmLaunch g;
         g.A = w.wqkv; g.lda = d; g.I = 3 * d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bqkv; g.out = QKV; g.ldo = 3 * d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        g.splitk_small = gs != nullptr;            // gradient mode only (see tvc_encode_image_backward)
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         if (pool_mode && l == a.layers - 1) {
             const PoolBufs pb = pool_bufs(h, a, n_seq, wso);
@@ -115,6 +116,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g = GemmLaunch();
         g.A = w.wo; g.lda = d; g.I = d; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.bo; g.out = D1; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        g.splitk_small = gs != nullptr;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * d * 8.0);
@@ -123,6 +125,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g = GemmLaunch();
         g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = H; g.ldb = d; g.J = rows; g.K = d;
         g.bias = w.b1; g.b_rows_padded = true; g.ldo = a.mlp;
+        g.splitk_small = gs != nullptr;
         if (gs) {
             // keep the pre-activation (what gelu' needs); the activation is one streaming pass over it
             uint16_t* U = gs->u + (size_t)l * rows * a.mlp;
@@ -136,6 +139,7 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
         g = GemmLaunch();
         g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = MLP; g.ldb = a.mlp; g.J = rows; g.K = a.mlp;
         g.bias = w.b2; g.out = D2; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
+        g.splitk_small = gs != nullptr;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
         pending = true;
     }
@@ -690,6 +694,9 @@ int tvc_encode_image_backward(tvc_handle* h, const float* grad_out_dev, float* g
         GemmLaunch g;
         g.A = (const uint16_t*)A; g.lda = lda; g.I = I; g.B = Bm; g.ldb = ldb; g.J = J; g.K = K;
         g.out = out; g.ldo = ldo; g.epilogue = epi; g.b_rows_padded = true;
+        // the gradient path promises no batch-position invariance of its last bits: a partial last round of tiles (FC1-shaped
+        // GEMMs at 32 images: 528 tiles = 2 rounds + 16 tiles) is split over K instead of taking a third round
+        g.splitk_small = true;
         HIP_TRY(timed_gemm(h, g, st, WS_SPLITK));
         return TVC_OK;
     };

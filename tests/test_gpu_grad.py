@@ -40,7 +40,10 @@ def test_layernorm_backward_vs_autograd(gpu_engine):
         assert (got0 - xr.grad).abs().max().item() < 2e-5 * max(1.0, xr.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("T,heads,n_seq", [(50, 12, 3), (257, 16, 2), (197, 12, 2), (17, 3, 5), (1, 2, 3)])
+@pytest.mark.parametrize("T,heads,n_seq", [(50, 12, 3), (257, 16, 2), (197, 12, 2), (17, 3, 5), (1, 2, 3),
+                                           # the straight-line 9-pair dK/dV form covers 257..288 tokens; its edges and the
+                                           # tile / pair boundaries below it
+                                           (258, 2, 2), (272, 2, 1), (273, 2, 1), (288, 2, 2), (256, 2, 2), (33, 2, 2), (32, 2, 2)])
 def test_attention_backward_vs_autograd(gpu_engine, T, heads, n_seq):
     eng = gpu_engine
     g0 = torch.Generator().manual_seed(T)

@@ -137,6 +137,21 @@ def test_attention(gpu_engine, n_seq, T, heads, causal):
     assert (got - ref).abs().mean().item() < 3e-3
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_length_sweep(gpu_engine, causal):
+    """Every tile / pair boundary of the sequence length (16 n, 16 n + 1, 32 n, 32 n + 1, the template switches at 32 / 64 /
+    96 tokens, the 257-token form's neighbours, the 288-token maximum): the fills clamp their row index and select zeros at
+    the LDS write, an unpaired last tile multiplies its own V rows by zeros, stores are 16-byte pieces after a lane swap."""
+    n_seq, heads = 3, 2
+    for T in (2, 15, 16, 17, 31, 32, 33, 48, 49, 63, 64, 65, 80, 96, 97, 128, 255, 256, 257, 258, 271, 272, 273, 288):
+        qkv = _rand((n_seq * T, 3 * heads * 64), 100 + T, 1.0).to(torch.bfloat16)
+        ref = _attn_ref(qkv, n_seq, T, heads, causal)
+        got = gpu_engine.attention(qkv.cuda(), n_seq, T, heads, causal).float().cpu()
+        assert torch.isfinite(got).all(), T
+        assert (got - ref).abs().max().item() < 3e-2, (T, (got - ref).abs().max().item())
+        assert (got - ref).abs().mean().item() < 3e-3, T
+
+
 def test_attention_spiky_scores(gpu_engine):
     """Large score range (one dominant key per query) must not overflow."""
     n_seq, T, heads = 2, 257, 2

@@ -37,7 +37,11 @@ def sd(pkg):
 
 @pytest.mark.parametrize("n,heads,dh,Tq,Tk", [(1, 8, 40, 4096, 4096), (2, 8, 80, 1024, 1024), (2, 8, 160, 256, 256),
                                              (3, 8, 160, 64, 64), (2, 8, 40, 1024, 77), (2, 8, 160, 64, 77),
-                                             (1, 2, 64, 100, 50), (1, 3, 8, 70, 130)])
+                                             (1, 2, 64, 100, 50), (1, 3, 8, 70, 130),
+                                             # enough (sample, head, 256-query block) items for the eight-wave form, which at
+                                             # head dims <= 48 runs two workgroups per CU on ONE staging register set: ragged
+                                             # query blocks, a ragged last key tile, odd / short key-tile counts
+                                             (22, 8, 40, 700, 700), (22, 8, 40, 600, 77), (24, 8, 32, 520, 130), (22, 8, 80, 700, 200)])
 def test_streaming_attention_vs_fp64(pkg, sd, n, heads, dh, Tq, Tk):
     k = sd[3]
     g = torch.Generator().manual_seed(Tq + dh)
@@ -49,7 +53,7 @@ def test_streaming_attention_vs_fp64(pkg, sd, n, heads, dh, Tq, Tk):
     ref = (s.softmax(-1) @ sp(v, Tk)).transpose(1, 2).reshape(n * Tq, C)
     r2, rm = rel(out, ref)
     print(f"[measured] streaming attention n={n} heads={heads} dh={dh} Tq={Tq} Tk={Tk}: rel L2 {r2:.2e}  max|d|/std {rm:.2e}")
-    assert r2 < 5e-3 and rm < 5e-2          # measured 2.1e-3 .. 2.3e-3 / 1.4e-2 .. 2.3e-2 (bf16 probabilities and outputs)
+    assert r2 < 5e-3 and rm < 5e-2          # measured 2.1e-3 .. 2.3e-3 / 1.4e-2 .. 3.4e-2 (bf16 probabilities and outputs; the max grows with the element count)
 
 
 @pytest.mark.parametrize("kind,prefix,cin,cout,hw", [(3, "down_blocks.0.resnets.0.conv1.", 320, 320, 16),

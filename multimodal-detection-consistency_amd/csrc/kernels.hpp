@@ -159,7 +159,8 @@ hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, cons
                         hipStream_t st);
 hipError_t sd_relayout(const uint16_t* in, uint16_t* out, int n, int H, int W, int C, int in_pad, int out_pad, int up, hipStream_t st);
 hipError_t sd_add_padded(const uint16_t* a, const uint16_t* b_padded, uint16_t* out, int n, int H, int W, int C, hipStream_t st);
-hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps, hipStream_t st);
+hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps, hipStream_t st,
+                             const uint16_t* add = nullptr, uint16_t* sum_out = nullptr);     // add: y = LN(bf16(x + add)), the sum also to sum_out
 hipError_t sd_geglu(const uint16_t* in, uint16_t* out, int64_t rows, int Ch, hipStream_t st);
 hipError_t sd_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, hipStream_t st);
 hipError_t sd_concat(const uint16_t* a, int Ca, const uint16_t* b, int Cb, uint16_t* out, int64_t tokens, hipStream_t st);

@@ -209,10 +209,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
-// ---- LayerNorm over channels, bf16 -> bf16, one wave per row, C % 8 == 0, C <= 1536
+// ---- LayerNorm over channels, bf16 -> bf16, one wave per row, C % 8 == 0, C <= 1536.
+// With `add` the row is first replaced by bf16(x + add), which is also written to `sum_out` (the residual stream a
+// transformer block carries on): the residual add and the LayerNorm that follows it in ONE pass, bit-identical to
+// add_bf16_kernel followed by this kernel (the sum is rounded to bf16 before it is normalised, as the stored one is).
 __global__ __launch_bounds__(256) void ln_bf16_kernel(const uint16_t* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, uint16_t* __restrict__ y, int64_t rows,
-                                                      int C, float eps) {
+                                                      int C, float eps, const uint16_t* __restrict__ add,
+                                                      uint16_t* __restrict__ sum_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -225,6 +229,15 @@ __global__ __launch_bounds__(256) void ln_bf16_kernel(const uint16_t* __restrict
         const int v = lane + i * 64;
         if (v < cv) {
             unpack8(xr[v], f[i]);
+            if (add) {
+                float a8[8];
+                unpack8(((const u32x4_t*)(add + row * C))[v], a8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] += f[i][e];
+                const u32x4_t pk = pack8(a8);
+                ((u32x4_t*)(sum_out + row * C))[v] = pk;
+                unpack8(pk, f[i]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += f[i][e];
         }
@@ -579,10 +592,10 @@ hipError_t sd_add_padded(const uint16_t* a, const uint16_t* b_padded, uint16_t* 
 }
 
 hipError_t sd_layernorm_bf16(const uint16_t* x, const float* g, const float* b, uint16_t* y, int64_t rows, int C, float eps,
-                             hipStream_t st) {
-    if (C % 8 != 0 || C > 1536) return hipErrorInvalidValue;
+                             hipStream_t st, const uint16_t* add, uint16_t* sum_out) {
+    if (C % 8 != 0 || C > 1536 || ((add != nullptr) != (sum_out != nullptr))) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ln_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL(ln_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, y, rows, C, eps, add, sum_out);
     return hipGetLastError();
 }
 

@@ -201,6 +201,18 @@ struct Run {
         }
         return y;
     }
+    // sum = a + b (the residual stream) and LayerNorm(sum) in one pass; bit-identical to add() followed by layernorm()
+    Act add_layernorm(const Act& a, const Act& b, const std::string& prefix, Act& sum) {
+        sum = act(a.n, a.H, a.W, a.C);
+        Act y = act(a.n, a.H, a.W, a.C);
+        const float* g = (const float*)W(prefix + "weight");
+        const float* bb = (const float*)W(prefix + "bias");
+        if (live()) {
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)a.tok() * a.C * 8.0);
+            hip(sd_layernorm_bf16(a.p, g, bb, y.p, a.tok(), a.C, 1e-5f, st, b.p, sum.p), "sd_add_layernorm");
+        }
+        return y;
+    }
     Act add(const Act& a, const Act& b) {
         Act y = act(a.n, a.H, a.W, a.C);
         if (live()) {
@@ -248,26 +260,27 @@ struct Run {
         const size_t mark = off;
         Act g = groupnorm(x, p + "norm.", 1e-6f, 0);
         Act hs = linear(g, p + "proj_in.weight", p + "proj_in.bias", C);
+        Act n2, n3, hs1;
         {   // self-attention
             Act n1 = layernorm(hs, t + "norm1.");
             Act qkv = linear(n1, t + "attn1.to_qkv.weight", "", 3 * C);
             Act a = act(n, x.H, x.W, C);
             attention(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, a.p, C, n, heads, T, T, dh);
             Act o = linear(a, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", C);
-            hs = add(hs, o);
+            n2 = add_layernorm(hs, o, t + "norm2.", hs1);      // hs1 = hs + o; n2 = norm2(hs1)
+            hs = hs1;
         }
         {   // cross-attention onto the text states
-            Act n2 = layernorm(hs, t + "norm2.");
             Act q = linear(n2, t + "attn2.to_q.weight", "", C);
             Act cx; cx.n = n; cx.H = 1; cx.W = S->d.ctx; cx.C = S->d.cross_attention_dim; cx.p = const_cast<uint16_t*>(ctx16);
             Act kv = linear(cx, t + "attn2.to_kv.weight", "", 2 * C);
             Act a = act(n, x.H, x.W, C);
             attention(q.p, C, kv.p, 2 * C, kv.p + C, 2 * C, a.p, C, n, heads, T, S->d.ctx, dh);
             Act o = linear(a, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", C);
-            hs = add(hs, o);
+            n3 = add_layernorm(hs, o, t + "norm3.", hs1);
+            hs = hs1;
         }
         {   // GEGLU feed-forward
-            Act n3 = layernorm(hs, t + "norm3.");
             Act gg = linear(n3, t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", 8 * C);
             Act ge = act(n, x.H, x.W, 4 * C);
             if (live()) {

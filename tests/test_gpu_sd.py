@@ -59,9 +59,9 @@ def test_streaming_attention_vs_fp64(pkg, sd, n, heads, dh, Tq, Tk):
 @pytest.mark.parametrize("kind,prefix,cin,cout,hw", [(3, "down_blocks.0.resnets.0.conv1.", 320, 320, 16),
                                                      (4, "down_blocks.1.downsamplers.0.conv.", 640, 640, 16),
                                                      (5, "up_blocks.1.upsamplers.0.conv.", 1280, 1280, 8)])
-def test_conv_kinds_vs_oracle(pkg, sd, kind, prefix, cin, cout, hw):
+def test_conv_kinds_vs_oracle(pkg, sd, kind, prefix, cin, cout, hw, n=2):
     arch, uw, vw, k = sd
-    x = torch.randn((2, cin, hw, hw), generator=torch.Generator().manual_seed(kind))
+    x = torch.randn((n, cin, hw, hw), generator=torch.Generator().manual_seed(kind))
     got = k.block(kind, prefix, x, cout)
     xs = x.to(torch.bfloat16).float()          # the block converts its fp32 input to bf16 rows
     F = torch.nn.functional
@@ -71,6 +71,15 @@ def test_conv_kinds_vs_oracle(pkg, sd, kind, prefix, cin, cout, hw):
     r2, rm = rel(got, ref)
     print(f"[measured] conv kind {kind} {prefix}: rel L2 {r2:.2e} max|d|/std {rm:.2e}")
     assert got.shape == ref.shape and r2 < 5e-3 and rm < 4e-2      # measured 2.35e-3 / 1.4e-2 .. 1.7e-2
+
+
+@pytest.mark.parametrize("prefix,cin,cout,hw", [("down_blocks.2.resnets.1.conv1.", 1280, 1280, 16),     # 6 144 tokens x 1280: 120 tiles
+                                                ("down_blocks.1.resnets.1.conv1.", 640, 640, 32)])      # 24 576 tokens x 640: 288 tiles
+def test_conv_at_generation_batch_takes_the_split_k_paths(pkg, sd, prefix, cin, cout, hw):
+    """24 samples (12 images x classifier-free guidance), the batch a generation runs at: the 16 x 16 level's convolutions are
+    launches of 64..128 tiles of a deep K (split two-way over K), the 32 x 32 level's 288 tiles = one round of whole tile columns
+    + a split-K tail (gemm.hip, launches that opted into split-K).  Same bound as the two-sample cases."""
+    test_conv_kinds_vs_oracle(pkg, sd, 3, prefix, cin, cout, hw, n=24)
 
 
 @pytest.mark.parametrize("prefix,cin,cout,hw,vae", [("down_blocks.0.resnets.0.", 320, 320, 32, False),

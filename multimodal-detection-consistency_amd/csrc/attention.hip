@@ -14,7 +14,12 @@
 //                               (k-slot order chosen to match the accumulator map)
 //
 // "Swapped" products keep the query on the lane (column) dimension, so row
-// statistics are per-lane scalars and the output is 8-byte row pieces.
+// statistics are per-lane scalars; a lane's output is 4 consecutive head dims per 16-wide tile, swapped between
+// neighbouring tiles (v_permlane16_swap) into 16-byte store pieces.
+//
+// What bounds it (in-kernel clock stamps, round 3): the memory system's rate on the packed rows' 128-byte
+// per-head pieces, not vector issue.  Hence the XCD-contiguous item order, the unconditional one-latency fill, the wait
+// for the next block's Q fragments placed BEFORE the block's stores (vmcnt counts stores), and the 16-byte stores.
 
 #include "common.hpp"
 #include "kernels.hpp"

@@ -152,6 +152,28 @@ def test_attention_length_sweep(gpu_engine, causal):
         assert (got - ref).abs().mean().item() < 3e-3, T
 
 
+def test_attention_nan_stays_inside_its_sequence_and_head(gpu_engine):
+    """A NaN in one (sequence, head)'s keys / values / queries makes THAT item's outputs NaN and leaves every other item
+    bit-identical (the kernels clamp row indices and multiply an unpaired last tile's own V rows by zero probabilities:
+    nothing of one item is ever read for another)."""
+    n_seq, T, heads = 4, 257, 3
+    qkv = _rand((n_seq * T, 3 * heads * 64), 21, 1.0).to(torch.bfloat16)
+    clean = gpu_engine.attention(qkv.cuda(), n_seq, T, heads, False).cpu()
+    bad = qkv.clone()
+    W = heads * 64
+    bad[1 * T + 256, 2 * W + 1 * 64 + 5] = float("nan")        # sequence 1, head 1: the LAST value row (the unpaired tile)
+    bad[2 * T + 7, 1 * W + 2 * 64 + 9] = float("nan")          # sequence 2, head 2: a key
+    got = gpu_engine.attention(bad.cuda(), n_seq, T, heads, False).cpu()
+    o = got.view(n_seq, T, heads, 64); c = clean.view(n_seq, T, heads, 64)
+    hit = torch.zeros((n_seq, heads), dtype=torch.bool); hit[1, 1] = True; hit[2, 2] = True
+    for s_ in range(n_seq):
+        for h_ in range(heads):
+            if hit[s_, h_]:
+                assert torch.isnan(o[s_, :, h_].float()).any()
+            else:
+                assert torch.equal(o[s_, :, h_].view(torch.int16), c[s_, :, h_].view(torch.int16)), (s_, h_)
+
+
 def test_attention_spiky_scores(gpu_engine):
     """Large score range (one dominant key per query) must not overflow."""
     n_seq, T, heads = 2, 257, 2

@@ -274,10 +274,30 @@ def main():
         dist.barrier()
         t = torch.tensor([1e-3 * (rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line = {"metric": "defended queries/sec", "value": 0.0, "unit": "queries/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "dry_run": True, "max_over_ranks_s": float(t.item()),
+                "distributed": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
+        if a.shard_bank:
+            # the sharded layout's collectives on stand-in tensors (no kernels): row split, all-gather of query rows, the
+            # fixed-size all-to-all, the status all-reduce -- the shapes of one configs[3] step divided by 1 000
+            sh = importlib.import_module("multimodal-detection-consistency_amd.sharding")
+            lo, hi = sh.shard_bounds(a.bank_rows, world, rank)
+            m, D = 8, 16
+            rows = torch.full((m, D), float(rank))
+            allrows = torch.empty((world * m, D))
+            dist.all_gather_into_tensor(allrows, rows)
+            send = torch.arange(world, dtype=torch.float32).view(world, 1).repeat(1, 4) + 100.0 * rank
+            recv = torch.empty_like(send)
+            sh._all_to_all(recv, send, None)
+            ok = bool((allrows.view(world, m, D)[:, 0, 0] == torch.arange(world)).all()) and \
+                bool((recv[:, 0] == 100.0 * torch.arange(world) + rank).all())
+            sizes = torch.tensor([float(hi - lo), 1.0 if ok else 0.0], dtype=torch.float64)
+            gathered = [torch.empty_like(sizes) for _ in range(world)]
+            dist.all_gather(gathered, sizes)
+            line["shard_rows"] = [int(g[0]) for g in gathered]
+            line["collectives_ok"] = all(bool(g[1] > 0) for g in gathered)
         if rank == 0:
-            print(json.dumps({"metric": "defended queries/sec", "value": 0.0, "unit": "queries/s", "n_gpus": world,
-                              "steps": a.steps, "warmup": a.warmup, "dry_run": True,
-                              "max_over_ranks_s": float(t.item())}), flush=True)
+            print(json.dumps(line), flush=True)
         dist.destroy_process_group()
         return
     pkg = importlib.import_module("multimodal-detection-consistency_amd")
@@ -353,7 +373,9 @@ def main():
         rows = torch.cat([fi, ft])
         idx, sim, feat = sharded.search(rows, k, cfg.reference_count, feat_from=B)
         rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, idx[B:].contiguous(), sim[B:].contiguous(), feat[B:].contiguous())
-        return rec.cpu(), idx[:B].cpu()
+        out = rec.cpu(), idx[:B].cpu()
+        sharded.check_status()            # once per step, INSIDE the timed region: every rank's overflow flag, all-reduced
+        return out
 
     def step_dp_pipelined():
         """The data-parallel step software-pipelined like `step_sharded_pipelined`: batch i + 1's towers are enqueued on their
@@ -397,7 +419,10 @@ def main():
             idx, sim, feat = sharded.search(rows, k, cfg.reference_count, feat_from=B)    # image rows need no reference rows
             rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, idx[B:].contiguous(), sim[B:].contiguous(),
                                   feat[B:].contiguous())
-            return rec.cpu(), idx[:B].cpu()
+            out = rec.cpu(), idx[:B].cpu()
+            if a.exchange == "fused":
+                sharded.check_status()    # the other exchange modes are status-checked per call
+            return out
         idx, sim, _ = eng.bank_search(rows, k, cfg.similarity_threshold, want_moments=False)
         tidx, tsim = idx[B:], sim[B:]
         feat = eng.bank_gather(tidx[:, :cfg.reference_count].contiguous())
@@ -414,8 +439,6 @@ def main():
             out = fn()
         if not a.shard_bank:
             eng.bank_status()
-        elif a.exchange == "fused":
-            sharded.check_status()            # the asynchronous search: one status read-back, outside the timed region
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -430,8 +453,6 @@ def main():
         dt = float(t.item())
     if not a.shard_bank:
         eng.bank_status()
-    elif a.exchange == "fused":
-        sharded.check_status()                # (the other exchange modes are status-checked per call)
     assert torch.isfinite(rec[:, :11]).all()      # words >= 12+N hold int32 bit patterns (-1 = NaN bits)
     kept_refs = float(rec[:, 8].mean())           # references kept per query by the consistency kernel
 
@@ -521,6 +542,15 @@ def main():
 
     if rank == 0 and a.shard_bank:
         out["exchange"] = dict(sharded.last_exchange)
+        out["exchange"]["status_check"] = ("check_status() once per step inside the timed region: the local overflow flag read back + "
+                                           "one all_reduce(MAX) of two floats" if a.exchange == "fused" else "per call (status-checked search)")
+    if rank == 0 and dist.is_initialized():
+        # what the process group itself reports -- so that a SCALE record shows RCCL (backend "nccl" on ROCm) really saw N ranks
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "ranks_on_distinct_gpus": not a.rehearse_one_gpu,
+                              "data_path_collectives": ("all_gather_into_tensor + all_to_all_single per step (bank rows sharded)"
+                                                        if a.shard_bank else "none (data-parallel queries, replicated bank)"),
+                              "timing": "barrier + synchronize on both sides, MAX over ranks (all_reduce)"}
     extras = world == 1 and not a.no_extras and not a.shard_bank
     if extras and not a.dense_text:
         # the same workload with the text tower on all 77 positions (no EOT packing): the rate does not
@@ -675,7 +705,7 @@ def main():
         # steps (experiments/defenses/generative_ref.py:24) at 64 x 64 latents, guidance 7.5, VAE decode to 512 x 512,
         # device-side preprocessing, ONE image-tower launch -> reference embeddings
         torch.cuda.empty_cache()
-        sd = pkg.StableDiffusionModel(pkg.SDModelConfig(device=str(dev)), clip_model=clip)
+        sd = pkg.StableDiffusionModel(pkg.SDModelConfig(device=str(dev), random_init=True), clip_model=clip)
         n_img, steps_sd = 12, 20
         prompts = [f"a photo of object number {i}" for i in range(n_img)]
         seeds_sd = list(range(n_img))

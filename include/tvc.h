@@ -178,9 +178,14 @@ const char* tvc_last_error(tvc_handle* h);
  * ~1e-6 of the reference's fp32 CPU path (src/detector.py:461-485; configs/attacks/pgd.yaml:80 asks for fp32), so the
  * consistency scores meet the 1e-4 bar END TO END.  About 10x slower; validation and attack-generation mode, never the
  * benchmarked one.  Needs tvc_set_weights_f32 first (TVC_E_STATE otherwise).  The input-gradient entry points
- * (tvc_encode_image_grad / _backward) always run the bf16 path. */
+ * (tvc_encode_image_grad / _backward) always run the bf16 path.
+ * TVC_OPT_SD_ARENA_BYTES (default 48 GiB): budget of the activation arena of ONE UNet evaluation inside tvc_sd_generate.
+ * The arena grows linearly with the samples of an evaluation (about 0.75 GB per image at 64 x 64 latents: both halves of
+ * classifier-free guidance); a batch that would exceed the budget is generated in chunks of whole sampling loops -- every
+ * image is independent of its batch mates, so chunking changes no pixel -- instead of failing with TVC_E_NOMEM. */
 enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
-       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6, TVC_OPT_TOWER_PRECISION = 7 };
+       TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6, TVC_OPT_TOWER_PRECISION = 7,
+       TVC_OPT_SD_ARENA_BYTES = 8 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
 
 /* Register fp32 copies of the tower weights for TVC_OPT_TOWER_PRECISION = 1 (either may be NULL).  Referenced, not

@@ -23,6 +23,7 @@ TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS, TVC_OPT
 TVC_OPT_TEXT_GROUP = 5
 TVC_OPT_POOLED_LAST_LAYER = 6
 TVC_OPT_TOWER_PRECISION = 7
+TVC_OPT_SD_ARENA_BYTES = 8
 
 
 class TVCError(RuntimeError):

@@ -83,6 +83,7 @@ struct tvc_handle {
     std::vector<tvc_layer_weights_f32> vlayers32, tlayers32;
     int tower_precision = 0;   // TVC_OPT_TOWER_PRECISION
     struct SdState* sd = nullptr;   // latent-diffusion model (tvc_sd.cpp), owned
+    size_t sd_arena_bytes = (size_t)48 << 30;   // TVC_OPT_SD_ARENA_BYTES: activation arena of one UNet evaluation
 };
 void tvc_sd_free(tvc_handle* h);    // tvc_sd.cpp
 

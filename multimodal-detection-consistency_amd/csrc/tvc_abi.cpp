@@ -801,6 +801,9 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
         case TVC_OPT_MAX_CHUNK_TEXTS:
             if (value < 1) return fail(h, TVC_E_INVALID, "tvc_set_option: chunk must be >= 1");
             h->max_chunk_texts = (int)value; return TVC_OK;
+        case TVC_OPT_SD_ARENA_BYTES:
+            if (value < ((int64_t)1 << 28)) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_SD_ARENA_BYTES must be >= 256 MiB");
+            h->sd_arena_bytes = (size_t)value; return TVC_OK;
         default: return fail(h, TVC_E_INVALID, "tvc_set_option: unknown option");
     }
 }

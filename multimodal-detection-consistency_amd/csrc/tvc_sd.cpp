@@ -309,7 +309,8 @@ struct Run {
         uint16_t* kc = (uint16_t*)alloc((size_t)Tp * C * 2);
         uint16_t* vT = (uint16_t*)alloc((size_t)(C + 512) * (size_t)((T + 63) / 64 * 64) * 2);     // [C, T]
         float* sc = (float*)alloc((size_t)T * T * 4);
-        uint16_t* pr = (uint16_t*)alloc((size_t)Tp * T * 2);
+        // `pr` holds the probabilities [T (readable to Tp), T] -- and, before them, the image's compact V rows [T, C]
+        uint16_t* pr = (uint16_t*)alloc(std::max((size_t)Tp * T, (size_t)T * C) * 2);
         if (T % 64 != 0 && rc == TVC_OK) rc = fail(h, TVC_E_INVALID, "tvc_sd: VAE attention needs H * W % 64 == 0");
         for (int i = 0; i < n && live(); ++i) {
             const uint16_t* rows = qkv.p + (int64_t)i * T * 3 * C;
@@ -457,6 +458,17 @@ int with_arena(tvc_handle* h, hipStream_t st, Slot slot, F&& body) {
     return run.rc;
 }
 
+// UNet2DConditionModel halves H, W (blocks - 1) times with ceil sizes and doubles them back: any size that is not a multiple
+// of 2^(blocks - 1) gives skip tensors whose token counts do not match the upsampled ones
+int check_latent_hw(tvc_handle* h, int H, int W, bool unet, bool vae, const char* who) {
+    const int ds = unet ? 1 << (h->sd->d.n_blocks - 1) : 1;
+    if (H < ds || W < ds || H % ds || W % ds)
+        return fail(h, TVC_E_INVALID, std::string(who) + ": H and W must be multiples of 2^(blocks - 1) = " + std::to_string(ds));
+    if (vae && ((int64_t)H * W) % 64 != 0)
+        return fail(h, TVC_E_INVALID, std::string(who) + ": the VAE's attention block needs H * W % 64 == 0");
+    return TVC_OK;
+}
+
 int need_sd(tvc_handle* h, bool unet, bool vae, const char* who) {
     if (!h) return TVC_E_INVALID;
     if (!h->sd || (unet && !h->sd->has_unet) || (vae && !h->sd->has_vae))
@@ -563,9 +575,8 @@ int tvc_sd_unet(tvc_handle* h, const float* latents_dev, int32_t n, int32_t H, i
                 float* eps_dev, void* stream) {
     int rc = need_sd(h, true, false, "tvc_sd_unet");
     if (rc) return rc;
-    const int ds = 1 << (h->sd->d.n_blocks - 1);
-    if (n < 1 || H < ds || W < ds || H % ds || W % ds || !latents_dev || !ctx_dev || !eps_dev)
-        return fail(h, TVC_E_INVALID, "tvc_sd_unet: need n >= 1, H and W multiples of 2^(blocks - 1), non-NULL buffers");
+    if (n < 1 || !latents_dev || !ctx_dev || !eps_dev) return fail(h, TVC_E_INVALID, "tvc_sd_unet: need n >= 1, non-NULL buffers");
+    if ((rc = check_latent_hw(h, H, W, true, false, "tvc_sd_unet"))) return rc;
     return with_arena(h, (hipStream_t)stream, WS_SD0,
                       [&](Run& R) { unet_forward(R, latents_dev, n, H, W, timestep, ctx_dev, eps_dev); });
 }
@@ -574,6 +585,7 @@ int tvc_sd_vae_decode(tvc_handle* h, const float* latents_dev, int32_t n, int32_
     int rc = need_sd(h, false, true, "tvc_sd_vae_decode");
     if (rc) return rc;
     if (n < 1 || H < 1 || W < 1 || !latents_dev || !images_dev) return fail(h, TVC_E_INVALID, "tvc_sd_vae_decode: bad arguments");
+    if ((rc = check_latent_hw(h, H, W, false, true, "tvc_sd_vae_decode"))) return rc;
     const tvc_sd_desc& d = h->sd->d;
     const int up = 1 << (d.vae_n_blocks - 1);
     // images in chunks that keep the im2col rows of the full-resolution layers within a few GB
@@ -592,16 +604,13 @@ int tvc_sd_vae_decode(tvc_handle* h, const float* latents_dev, int32_t n, int32_
     return TVC_OK;
 }
 
-int tvc_sd_generate(tvc_handle* h, const float* cond_dev, const float* uncond_dev, float* latents_dev, int32_t n, int32_t H,
-                    int32_t W, int32_t steps, float guidance, float* images_dev, void* stream) {
-    int rc = need_sd(h, true, images_dev != nullptr, "tvc_sd_generate");
-    if (rc) return rc;
+// the sampling loop for m images whose conditioning / latents start at the given pointers
+static int sd_generate_chunk(tvc_handle* h, const float* cond_dev, const float* uncond_dev, float* latents_dev, int n, int H, int W,
+                             int steps, float guidance, hipStream_t st) {
     SdState* S = h->sd;
     const tvc_sd_desc& d = S->d;
     const int T = (int)S->alphas_cumprod.size();
-    if (n < 1 || steps < 2 || steps > T || !cond_dev || !uncond_dev || !latents_dev)
-        return fail(h, TVC_E_INVALID, "tvc_sd_generate: need n >= 1, 2 <= steps <= num_train_timesteps, non-NULL buffers");
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
     const int64_t ne = (int64_t)n * d.in_channels * H * W;          // elements of the latents
     const size_t ctx_elems = (size_t)n * d.ctx * d.cross_attention_dim;
     // [uncond | cond] text states, doubled latents, eps of both halves, 4 history slots, the saved sample of the 2nd step
@@ -663,6 +672,39 @@ int tvc_sd_generate(tvc_handle* h, const float* cond_dev, const float* uncond_de
         const float denom = a_t * sqrtf(b_prev) + sqrtf(a_t * b_t * a_prev);
         HIP_TRY(sd_lincomb(latents_dev, sample, cs, (a_prev - a_t) / denom, e0, c0, e1, c1, e2, c2, e3, c3, ne, st));
         ++counter;
+    }
+    return TVC_OK;
+}
+
+int tvc_sd_generate(tvc_handle* h, const float* cond_dev, const float* uncond_dev, float* latents_dev, int32_t n, int32_t H,
+                    int32_t W, int32_t steps, float guidance, float* images_dev, void* stream) {
+    int rc = need_sd(h, true, images_dev != nullptr, "tvc_sd_generate");
+    if (rc) return rc;
+    SdState* S = h->sd;
+    const tvc_sd_desc& d = S->d;
+    const int T = (int)S->alphas_cumprod.size();
+    if (n < 1 || steps < 2 || steps > T || !cond_dev || !uncond_dev || !latents_dev)
+        return fail(h, TVC_E_INVALID, "tvc_sd_generate: need n >= 1, 2 <= steps <= num_train_timesteps, non-NULL buffers");
+    if ((rc = check_latent_hw(h, H, W, true, images_dev != nullptr, "tvc_sd_generate"))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // Samples per pass: the activations of ONE UNet evaluation live in one arena (nothing is recomputed), whose size is
+    // linear in the sample count -- a dry run of one image's (unconditional | conditional) pair measures it, and the batch
+    // runs in chunks that keep the arena within TVC_OPT_SD_ARENA_BYTES.  A chunk is a whole sampling loop of its images
+    // (every sample's arithmetic is independent of its batch mates), so chunking changes no image.
+    Run dry{h, S, st, true};
+    dry.splitk = (float*)dry.alloc(Run::SPLITK_BYTES);
+    unet_forward(dry, nullptr, 2, H, W, 0.f, nullptr, nullptr);
+    if (dry.rc != TVC_OK) return dry.rc;
+    const size_t per_image = dry.high > Run::SPLITK_BYTES ? dry.high - Run::SPLITK_BYTES : dry.high;
+    int64_t chunk = (int64_t)((h->sd_arena_bytes > Run::SPLITK_BYTES ? h->sd_arena_bytes - Run::SPLITK_BYTES : 0) / (per_image ? per_image : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    const size_t lat_per = (size_t)d.in_channels * H * W, ctx_per = (size_t)d.ctx * d.cross_attention_dim;
+    for (int i0 = 0; i0 < n; i0 += (int)chunk) {
+        const int m = n - i0 < chunk ? n - i0 : (int)chunk;
+        rc = sd_generate_chunk(h, cond_dev + (size_t)i0 * ctx_per, uncond_dev + (size_t)i0 * ctx_per, latents_dev + (size_t)i0 * lat_per,
+                               m, H, W, steps, guidance, st);
+        if (rc) return rc;
     }
     if (images_dev) return tvc_sd_vae_decode(h, latents_dev, n, H, W, images_dev, stream);
     return TVC_OK;

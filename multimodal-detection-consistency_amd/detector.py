@@ -14,6 +14,7 @@ host: the stateful adaptive threshold / confidence of ``ConsistencyChecker``.
 """
 from __future__ import annotations
 
+import logging
 import threading
 import time
 from dataclasses import dataclass, field
@@ -26,6 +27,8 @@ from . import _lib
 from .clip import CLIPConfig, CLIPModel
 from .engine import ConsistencyConfig
 from .variants import as_generator, batch_variants
+
+logger = logging.getLogger(__name__)
 
 SRC_WEIGHTS = {"text_variants": 0.4, "sd_reference": 0.4, "consistency": 0.2}   # src/detector.py:666-670
 
@@ -197,23 +200,37 @@ class AdversarialDetector:
         # (sd_ref.SDReferenceGenerator over sd_model.StableDiffusionModel: tvc_sd_generate).  ONE encode of all
         # reference images, one consistency launch per distinct count (cos(image, ref_j) = record words 0, 12..).
         sd_pending, sd_counts = [], [0] * n
+        sd_errors: Dict[int, str] = {}                      # query -> message: the method scores 0.0 + 'error' (:555-557)
         if sd_on:
             fr = None
             if reference_images is None and hasattr(self.sd_generator, "reference_features"):
                 # a generator of this package: every prompt x seed of the batch in the SAME UNet launches, references
-                # preprocessed on the device and encoded in one image-tower launch (sd_ref.SDReferenceGenerator)
-                if getattr(self.sd_generator, "clip_model", None) is None:
-                    self.sd_generator.clip_model = clip
-                fr, sd_counts = self.sd_generator.reference_features(list(texts), self.config.num_reference_images)
-                sd_counts = list(sd_counts)
+                # preprocessed on the device and encoded in one image-tower launch (sd_ref.SDReferenceGenerator).
+                # A failure of the generation (no model, out of memory, ...) is the sd_reference method's failure only:
+                # src/detector.py:555-557 returns 0.0 + {'error'} for it and the other methods carry on
+                try:
+                    if getattr(self.sd_generator, "clip_model", None) is None:
+                        self.sd_generator.clip_model = clip
+                    fr, sd_counts = self.sd_generator.reference_features(list(texts), self.config.num_reference_images)
+                    sd_counts = list(sd_counts)
+                    if len(sd_counts) != n or sum(sd_counts) != (0 if fr is None else fr.shape[0]):
+                        raise RuntimeError("reference_features returned inconsistent counts")
+                except Exception as e:                      # noqa: BLE001
+                    logger.error("SD reference generation failed: %s", e)
+                    fr, sd_counts = None, [0] * n
+                    sd_errors = {i: str(e) for i in range(n)}
             else:
                 per_q = []
                 for i in range(n):
-                    if reference_images is not None:
-                        refs = reference_images[i]
-                    else:
-                        refs = self.sd_generator.generate_reference_images(
-                            texts[i], num_images=self.config.num_reference_images).get("images", [])
+                    try:
+                        if reference_images is not None:
+                            refs = reference_images[i]
+                        else:
+                            refs = self.sd_generator.generate_reference_images(
+                                texts[i], num_images=self.config.num_reference_images).get("images", [])
+                    except Exception as e:                  # noqa: BLE001 -- :555-557, this query's sd method only
+                        logger.error("SD reference generation failed for query %d: %s", i, e)
+                        refs, sd_errors[i] = [], str(e)
                     per_q.append(list(refs) if refs is not None else [])
                 sd_counts = [len(r) for r in per_q]
                 all_refs = [im for r in per_q for im in r]
@@ -256,7 +273,7 @@ class AdversarialDetector:
             for i in range(n):
                 if sd_counts[i] == 0:
                     scores[i]["sd_reference"] = 0.0                                      # :524-525
-                    details[i]["sd_reference"] = {"error": "no reference images"}
+                    details[i]["sd_reference"] = {"error": sd_errors.get(i, "no reference images")}
             for J, ids, rec_dev in sd_pending:
                 r = rec_dev.cpu().numpy().astype(np.float64)
                 sims = np.concatenate([r[:, 0:1], r[:, 12:12 + J - 1]], axis=1)

@@ -10,8 +10,11 @@ Everything between the token ids and the pixels runs on the GPU: CLIP ViT-L/14 t
 and the VAE decoder (``tvc_sd_generate``).  ``generate_batch`` is the batched form the reference does not have: all
 prompts x seeds of a batch share every UNet launch.
 
-There is no network: weights are the seeded random init of ``sd_arch.make_sd_weights`` unless a pair of diffusers
-safetensors files (``unet``, ``vae``) is given.
+Weights: a pair of diffusers safetensors files (``SDModelConfig(unet_weights=, vae_weights=)``), tensors handed in
+(``weights=``), or -- ONLY with the explicit opt-in ``SDModelConfig(random_init=True)`` -- the seeded random init of
+``sd_arch.make_sd_weights`` (there is no network for a checkpoint; benchmarks and parity tests run on it).  Without
+weights and without the opt-in the constructor raises, as the reference's pipeline load fails without a checkpoint
+(``src/sd_ref.py:291-317`` then goes on without a model and reports an error per call).
 """
 from __future__ import annotations
 
@@ -20,6 +23,8 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Union
 
+import logging
+
 import numpy as np
 import torch
 
@@ -27,6 +32,8 @@ from . import _lib, synth
 from .arch import get_arch
 from .engine import TVCEngine, _ptr, _stream
 from .sd_arch import SDArch, make_sd_weights, unet_param_shapes, vae_decoder_param_shapes
+
+logger = logging.getLogger(__name__)
 
 
 def _conv3x3_rows(w: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
@@ -190,6 +197,7 @@ class SDModelConfig:
     model_name: str = "runwayml/stable-diffusion-v1-5"      # src/sd_ref.py:220
     device: str = "cuda"
     seed: int = 0                                           # random-init seed (no checkpoint without a network)
+    random_init: bool = False                               # explicit opt-in: seeded random UNet / VAE (/ text tower) weights
     unet_weights: Optional[str] = None                      # diffusers unet / vae safetensors files, if present
     vae_weights: Optional[str] = None
     text_model: str = "ViT-L/14"                            # text_encoder/config.json: CLIP ViT-L/14 text tower
@@ -209,21 +217,35 @@ class StableDiffusionModel:
         dev = self.config.device
         self.device = torch.device("cuda:0" if dev in ("cuda", "auto") else dev)
         # conditioning tower: the caller's CLIP when its text tower has the UNet's cross-attention width
+        if bool(self.config.unet_weights) != bool(self.config.vae_weights):
+            raise ValueError("SDModelConfig: unet_weights and vae_weights must be given together (one alone would leave the "
+                             "other half of the model at random weights)")
+        have_files = bool(self.config.unet_weights and self.config.vae_weights)
+        if weights is None and not have_files and not self.config.random_init:
+            raise RuntimeError(f"no weights for '{self.config.model_name}': pass unet_weights= / vae_weights= (diffusers "
+                               "safetensors) or weights=, or opt into seeded random weights with SDModelConfig(random_init=True)")
         if clip_model is not None and clip_model.arch.text.width == self.arch.cross_attention_dim:
             self.text_engine, self.text_arch, self.tokenizer = clip_model.engine, clip_model.arch, clip_model.tokenizer
         else:
             self.text_arch = get_arch(self.config.text_model)
             if self.text_arch.text.width != self.arch.cross_attention_dim:
                 raise ValueError("the text tower's width must equal the UNet's cross_attention_dim")
+            if not self.config.random_init:
+                raise RuntimeError("the caller's CLIP text tower does not have the UNet's cross-attention width and no "
+                                   "conditioning tower was given: only SDModelConfig(random_init=True) builds a random one")
+            logger.warning("latent-diffusion conditioning tower: seeded RANDOM %s text weights + hash tokenizer (random_init)",
+                           self.text_arch.name)
             _, tw = synth.make_clip_weights(self.text_arch, self.config.seed)
             self.text_engine = TVCEngine(self.text_arch, None, tw, device=str(self.device))
             self.tokenizer = (BPETokenizer(self.config.tokenizer_dir, self.text_arch.ctx) if self.config.tokenizer_dir
                               else HashTokenizer(self.text_arch.ctx))
         if weights is None:
-            if self.config.unet_weights and self.config.vae_weights:
+            if have_files:
                 from safetensors.torch import load_file
                 weights = (load_file(self.config.unet_weights), load_file(self.config.vae_weights))
             else:
+                logger.warning("latent-diffusion model '%s': seeded RANDOM UNet / VAE weights (random_init=True) -- its images "
+                               "are noise; for benchmarks and parity tests only", self.config.model_name)
                 weights = make_sd_weights(self.arch, self.config.seed)
         self.kernels = SDKernels(self.text_engine, self.arch, weights[0], weights[1])
         self.generation_count = 0

@@ -147,6 +147,12 @@ class SDReferenceConfig:
     enable_cache: bool = True
     cache_dir: Optional[str] = None
     batch_size: int = 4
+    # not in the reference: where the in-tree model's weights come from (diffusers safetensors), or the explicit opt-in to
+    # seeded random weights (benchmarks / parity tests); with neither, building the model fails as the reference's
+    # pipeline load does without a checkpoint, and every generation call reports an error (:291-317)
+    unet_weights: Optional[str] = None
+    vae_weights: Optional[str] = None
+    random_init: bool = False
 
     def __post_init__(self):
         if self.variant_methods is None:
@@ -165,8 +171,10 @@ class SDReferenceGenerator:
             # (every generation call then reports an error instead of raising) -- mirrored
             try:
                 from .sd_model import SDModelConfig, StableDiffusionModel
-                sd_model = StableDiffusionModel(SDModelConfig(model_name=self.config.sd_model, device=self.config.device),
-                                                clip_model=clip_model)
+                sd_model = StableDiffusionModel(SDModelConfig(model_name=self.config.sd_model, device=self.config.device,
+                                                              unet_weights=self.config.unet_weights,
+                                                              vae_weights=self.config.vae_weights,
+                                                              random_init=self.config.random_init), clip_model=clip_model)
             except Exception as e:                                 # noqa: BLE001
                 logger.error("could not build the latent-diffusion model: %s", e)
                 sd_model = None

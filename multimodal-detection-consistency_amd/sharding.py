@@ -165,12 +165,18 @@ class ShardedBankSearch:
         if self.mode == "two_phase" and rows_per_shard is None:
             raise ValueError("the two-phase exchange needs rows_per_shard")
         self.last_exchange = {}
+        self._unchecked = False     # a fused search whose overflow status has not been read yet (check_status clears it)
 
     # ---- the sync-free form ------------------------------------------------------------------------------
     def search_fused(self, rows: torch.Tensor, k: int, kf: int, feat_from: int = 0):
         """(a) all-gather of the query rows, (b) asynchronous local search + gather of the kf best rows of every row
         that needs references, (c) ONE all-to-all of fixed-size slots [idx | sim | rows], (d) merge.  Nothing here
         reads a value back to the host: call ``check_status`` once per step."""
+        if self._unchecked:
+            # the fused search never reads its overflow flag: a caller that skips check_status would get silently
+            # truncated candidate lists from a degenerate shard -- refuse to run a second step on top of an unread one
+            raise RuntimeError("ShardedBankSearch(mode='fused'): call check_status() once per step (after search) -- the "
+                               "previous search's overflow status was never read; mode='two_phase' / 'single_phase' check per call")
         W, (m, D), dev = self.world, rows.shape, rows.device
         need = m - feat_from
         allrows = torch.empty((W * m, D), dtype=rows.dtype, device=dev)
@@ -206,6 +212,7 @@ class ShardedBankSearch:
             midx, msim = hi, hs
         self.last_exchange = {"mode": "fused", "bytes_per_peer": int(slot), "host_syncs": 0,
                               "rows_sent": int(W * need * kf), "bytes_per_row": D * esz}
+        self._unchecked = True
         return midx, msim, out_feat
 
     def check_status(self) -> None:
@@ -213,12 +220,24 @@ class ShardedBankSearch:
         rank dropped candidates (degenerate shard); the caller then repeats the step with ``mode="two_phase"`` /
         the status-checked search, whose brute-force fallback is local to the shard."""
         from . import _lib
-        over = bool(getattr(self.ops, "check", lambda: False)())
+        # every rank must reach the all_reduce whatever its local check did: a rank that raised before it would leave the
+        # others hanging in the collective.  Two flags travel: [overflow, any other error].
+        over, other = False, None
+        try:
+            over = bool(getattr(self.ops, "check", lambda: False)())
+        except Exception as e:                                   # noqa: BLE001 -- re-raised below, after the collective
+            other = e
+        finally:
+            self._unchecked = False
         if self.world > 1:
-            t = torch.tensor([1.0 if over else 0.0])
+            t = torch.tensor([1.0 if over else 0.0, 1.0 if other is not None else 0.0])
             t = t.cuda() if dist.get_backend(self.group) == "nccl" else t
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            over = bool(t.item() > 0)
+            over = bool(t[0].item() > 0)
+            if other is None and t[1].item() > 0:
+                other = RuntimeError("sharded bank search: another rank's status check failed")
+        if other is not None:
+            raise other
         if over:
             raise _lib.TVCError(_lib.TVC_E_OVERFLOW, "sharded bank search: a shard's candidate lists overflowed")
 

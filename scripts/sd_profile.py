@@ -5,7 +5,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 pkg = importlib.import_module("multimodal-detection-consistency_amd")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-sd = pkg.StableDiffusionModel(pkg.SDModelConfig())
+sd = pkg.StableDiffusionModel(pkg.SDModelConfig(random_init=True))
 eng = sd.text_engine
 prompts = [f"a photo of object number {i}" for i in range(n)]
 sd.generate_batch(prompts, list(range(n)), steps, 7.5, 512, 512)

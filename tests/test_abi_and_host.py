@@ -163,6 +163,27 @@ def test_bench_gpus_flag_launches_ranks_dry_run():
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["max_over_ranks_s"] == pytest.approx(2e-3)
 
 
+def test_bench_gpus_8_shard_bank_dry_run():
+    """BASELINE configs[3]'s launch line -- `bench.py --gpus 8 --shard-bank` -- with 8 real ranks (gloo, no GPU): the row
+    split of the 10 M-row bank, the all-gather of query rows, the fixed-size all-to-all and the status all-reduce run on
+    stand-in tensors; the line reports what the process group itself says (backend, world_size)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--shard-bank", "--dry-run-launch", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["max_over_ranks_s"] == pytest.approx(8e-3)
+    assert out["distributed"] == {"backend": "gloo", "world_size": 8}
+    assert out["shard_rows"] == [1_250_000] * 8 and out["collectives_ok"] is True
+
+
 def test_oracle_empty_component_semantics():
     """src/detector.py:375-383,457-458,524-525: a requested method whose component exists but yields nothing still
     contributes its 0.0 score; it is omitted only when the component is absent."""

@@ -408,6 +408,42 @@ def test_sd_reference_generator_feeds_the_detector(pkg, clip, images):
         assert res[i]["detection_details"]["sd_reference"]["num_references"] == 3
 
 
+def test_sd_generation_failure_is_the_sd_methods_failure_only(pkg, clip, images):
+    """src/detector.py:555-557: when reference generation fails, ``_detect_by_sd_reference`` returns 0.0 + {'error'} and the
+    other methods' results stand -- with a batched generator (``reference_features``) that raises, with a per-prompt
+    generator (``generate_reference_images``) that raises for one query, and with the in-tree generator that has no model
+    (no weights and no random_init opt-in: the reference's load failure, src/sd_ref.py:291-317)."""
+    class Boom:
+        clip_model = None
+
+        def reference_features(self, prompts, num_images=None):
+            raise RuntimeError("out of memory (simulated)")
+
+    class BoomOne:
+        def generate_reference_images(self, text, num_images=None):
+            if text == TEXTS[1]:
+                raise RuntimeError("pipeline crashed (simulated)")
+            g = torch.Generator().manual_seed(len(text))
+            return {"images": [torch.randn((3, 64, 64), generator=g) for _ in range(num_images)]}
+
+    cfg = pkg.DetectorConfig(clip_model="ViT-T/16-test", num_reference_images=2)
+    base = pkg.AdversarialDetector(cfg, clip_model=clip).batch_detect(images[:3], TEXTS[:3], methods=["text_variants", "consistency"])
+    for sdg, bad in ((Boom(), {0, 1, 2}), (BoomOne(), {1}),
+                     (pkg.SDReferenceGenerator(pkg.SDReferenceConfig(use_text_variants=False, filter_low_quality=False), clip_model=clip),
+                      {0, 1, 2})):
+        res = pkg.AdversarialDetector(cfg, clip_model=clip, sd_generator=sdg).batch_detect(images[:3], TEXTS[:3])
+        for i in range(3):
+            s = res[i]["detection_scores"]
+            assert abs(s["text_variants"] - base[i]["detection_scores"]["text_variants"]) < 1e-7
+            assert abs(s["consistency"] - base[i]["detection_scores"]["consistency"]) < 1e-7
+            if i in bad:
+                assert s["sd_reference"] == 0.0 and "error" in res[i]["detection_details"]["sd_reference"]
+                want = (0.4 * s["text_variants"] + 0.4 * 0.0 + 0.2 * s["consistency"]) / 1.0      # :664-680: the 0.0 enters
+                assert abs(res[i]["aggregated_score"] - want) < 1e-6
+            else:
+                assert res[i]["detection_details"]["sd_reference"]["num_references"] == 2
+
+
 def test_defense_detector_generative_branch(pkg, clip, images):
     """experiments/defenses/detector.py:206-226,268-300 with an injected generator (the diffusion model itself is
     not built): references for the first three of (original + variants), cut to generation_count, cos(image, ref)

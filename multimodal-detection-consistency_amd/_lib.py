@@ -18,7 +18,7 @@ HEADER_PATH = PKG_DIR.parent / "include" / "tvc.h"
 TVC_OK, TVC_E_INVALID, TVC_E_HIP, TVC_E_NOMEM, TVC_E_STATE, TVC_E_OVERFLOW = range(6)
 TVC_DTYPE_BF16, TVC_DTYPE_F32 = 0, 1
 TVC_REC_HEAD, TVC_REC_MAXREF = 12, 16
-TVC_ABI_VERSION, TVC_MAX_BANKS, TVC_MAX_TOPK = 3, 8, 128
+TVC_ABI_VERSION, TVC_MAX_BANKS, TVC_MAX_TOPK = 4, 8, 128
 TVC_OPT_TEXT_PACKING, TVC_OPT_MAX_CHUNK_IMAGES, TVC_OPT_MAX_CHUNK_TEXTS, TVC_OPT_BANK_FILTER = 1, 2, 3, 4
 TVC_OPT_TEXT_GROUP = 5
 TVC_OPT_POOLED_LAST_LAYER = 6
@@ -123,6 +123,8 @@ SIGNATURES = {
     "tvc_set_weights_f32": (C.c_int, [_P, C.POINTER(VisionWeights), C.POINTER(TextWeights)]),
     "tvc_gemm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "tvc_attention_f32": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "tvc_gemm_split": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "tvc_attention_split": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     # latent-diffusion reference generator
     "tvc_sd_load": (C.c_int, [_P, C.POINTER(SDDesc), C.POINTER(NamedTensor), C.c_int32, _P]),
     "tvc_sd_unet": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),

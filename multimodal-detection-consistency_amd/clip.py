@@ -41,7 +41,8 @@ class CLIPConfig:
     #                                       file holding a transformers.CLIPModel state dict
     seed: int = 0
     tokenizer_dir: Optional[str] = None   # directory with CLIP BPE vocab.json + merges.txt
-    precision: str = "bf16"               # "fp32": fp32-grade towers (the reference's fp32 path to ~1e-6; ~10x slower)
+    precision: str = "bf16"               # "split": fp32-grade towers at ~1/3 of the bf16 rate (scores within 1e-4 end to end);
+                                          # "fp32": the exact-f32 reference mode (~1e-6; ~15x slower)
 
 
 class HashTokenizer:

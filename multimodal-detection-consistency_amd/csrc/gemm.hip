@@ -536,7 +536,31 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     // invariance to protect) and have 64..128 tiles of a DEEP K (a 3 x 3 convolution at 16 x 16 latents: 120 tiles x 180
     // K-tiles) also take the split-K kernels below instead of one tile per workgroup on half the chip.
     const int nk64_all = (int)((int64_t)L.K * L.planes / GEMM_BK);
-    const bool mid_split = L.splitk_small && L.splitk_ws && forced < 0 && ntiles >= ring_min && ntiles <= 128 && nk64_all >= 32 &&
+    const bool auto_split = L.splitk_fixed == 0;       // splitk_fixed: the caller fixed the K split (kernels.hpp)
+    if (L.splitk_fixed >= 2) {
+        int S = L.splitk_fixed;
+        if (S > nk64_all) S = nk64_all;
+        if (!L.splitk_ws || (size_t)ntiles * S * GEMM_BM * GEMM_BN * 4 > L.splitk_ws_bytes) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(ntiles * S), block, GEMM_LDS_BYTES, stream, g, L.splitk_ws, nIt, 0, S);
+        switch (L.epilogue) {
+            case TVC_EPI_F32:
+                hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_F32>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                break;
+            case TVC_EPI_BF16:
+                hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_BF16>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                break;
+            case TVC_EPI_GELU_BF16:
+                hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_GELU_BF16>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                break;
+            case TVC_EPI_RESID_F32:
+                hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_RESID_F32>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    const bool mid_split = auto_split && L.splitk_small && L.splitk_ws && forced < 0 && ntiles >= ring_min && ntiles <= 128 && nk64_all >= 32 &&
                            (size_t)ntiles * (256 / ntiles) * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes;
     const bool ring = deep && !mid_split && (forced >= 0 ? (forced >= 1 && ntiles >= 8) : (ntiles >= ring_min));
     if (ring) {
@@ -555,7 +579,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         if (S > nk64 / 4) S = nk64 / 4;
         if (S > 16) S = 16;
         const bool whole_rounds = (jt_full * nIt) % 256 == 0;
-        const bool tail = forced < 0 && L.splitk_ws && jt_full >= 1 && left >= 1 && S >= 2 &&
+        const bool tail = auto_split && forced < 0 && L.splitk_ws && jt_full >= 1 && left >= 1 && S >= 2 &&
                           ((tail_on && whole_rounds && left <= 64) || (L.splitk_small && left <= 128)) &&
                           (size_t)left * S * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes;
         if (tail) {
@@ -641,7 +665,7 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         int S = ntiles > 0 ? 256 / ntiles : 0;
         if (S > nk64 / 2) S = nk64 / 2;
         if (S > 16) S = 16;
-        if ((small_on || L.splitk_small) && forced < 0 && L.splitk_ws && S >= 2 &&
+        if (auto_split && (small_on || L.splitk_small) && forced < 0 && L.splitk_ws && S >= 2 &&
             (size_t)ntiles * S * GEMM_BM * GEMM_BN * 4 <= L.splitk_ws_bytes) {
             hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(ntiles * S), block, GEMM_LDS_BYTES, stream, g,
                                L.splitk_ws, nIt, 0, S);

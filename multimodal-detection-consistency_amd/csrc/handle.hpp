@@ -26,6 +26,9 @@ enum Slot {
     // fp32-grade towers (TVC_OPT_TOWER_PRECISION = 1): vision set, then the text set (+ WS_P_N)
     WS_PX, WS_PH, WS_PQKV, WS_PMLP, WS_PCLS, WS_P_N_END,
     WS_PTX = WS_P_N_END, WS_PTH, WS_PTQKV, WS_PTMLP, WS_PTCLS, WS_PEOT,
+    // split-bf16 towers (TVC_OPT_TOWER_PRECISION = 2, tvc_split.cpp): vision set, then the text set (+ WS_S_N)
+    WS_SX, WS_SH, WS_SQKV, WS_SU, WS_SM, WS_SDELTA1, WS_SDELTA2, WS_SCLS, WS_S_END,
+    WS_STX = WS_S_END, WS_STH, WS_STQKV, WS_STU, WS_STM, WS_STDELTA1, WS_STDELTA2, WS_STCLS,
     // latent-diffusion reference generator (tvc_sd.cpp)
     WS_SD0, WS_SD1, WS_SD2, WS_SD3, WS_SD4, WS_SD5, WS_SD6, WS_SD7,
     WS_COUNT
@@ -44,6 +47,11 @@ struct BankSlot {
     int planes = 1;
     float* bounds = nullptr;          // device [2]: max row norms of the bank planes
 };
+
+constexpr int WS_S_N = WS_S_END - WS_SX;      // offset from a vision split slot to its text twin
+
+// hi | lo bf16 planes [round_up(out, 256), 2 * in] of one layer's GEMM weights (split-bf16 mode), handle-owned
+struct SplitLayer { uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr; };
 
 struct ProfRec {
     hipEvent_t a, b;
@@ -82,10 +90,17 @@ struct tvc_handle {
     tvc_text_weights_f32 tw32{};
     std::vector<tvc_layer_weights_f32> vlayers32, tlayers32;
     int tower_precision = 0;   // TVC_OPT_TOWER_PRECISION
+    // split-bf16 mode (precision 2): planes of every GEMM weight, built from the fp32 copies when the option is set
+    std::vector<SplitLayer> vsplit, tsplit;
+    uint16_t* vsplit_patch = nullptr;
+    std::vector<void*> split_owned;
+    bool split_ready = false;
     struct SdState* sd = nullptr;   // latent-diffusion model (tvc_sd.cpp), owned
     size_t sd_arena_bytes = (size_t)48 << 30;   // TVC_OPT_SD_ARENA_BYTES: activation arena of one UNet evaluation
 };
 void tvc_sd_free(tvc_handle* h);    // tvc_sd.cpp
+void tvc_split_free(tvc_handle* h); // tvc_split.cpp
+int tvc_split_prepare(tvc_handle* h);
 
 inline int fail(tvc_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_error = msg;

@@ -16,6 +16,10 @@ struct GemmLaunch {
     int b_plane_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool splitk_small = false;     // launches of fewer tiles than CUs may split K over the idle CUs (needs splitk_ws; the fp32 sums are
                                    // then taken in a different order than in the one-pass kernels)
+    int splitk_fixed = 0;          // 0: the launch decides (above).  1: never split.  S >= 2: split K exactly S ways for EVERY tile
+                                   // (needs splitk_ws of tiles * S * 256 KiB) -- callers that promise results independent of the
+                                   // launch size (the latent-diffusion model: an image must not depend on its batch mates) pick S
+                                   // from the per-sample shape, never from J
     bool a_rows_padded = false;    // A has readable rows up to the next multiple of 256 beyond I (form 4 with a ragged last row tile)
     const float* bias = nullptr;   // [I]
     void* out = nullptr;           // [J, ldo]
@@ -149,6 +153,16 @@ hipError_t launch_attention_f32(const float* qkv, float* out, int n_seq, int T, 
 hipError_t launch_im2col_f32(const float* pix, float* out, int B, int image, int patch, hipStream_t stream);
 hipError_t launch_gather_f32_rows(const float* x, int64_t ld, const int32_t* idx, int64_t idx_mul, float* out, int n,
                                   int d, hipStream_t stream);
+
+// ---- split.hip: split-bf16 towers (hi | lo bf16 planes [rows, 2K], three MFMA products per element)
+// LayerNorm of x (+ fp32 deltas d1, d2; written back to x when write_x) -> planes [rows, 2d] and / or fp32 rows y32
+hipError_t launch_ln_split(float* x, int64_t x_row_stride, const int32_t* row_idx, const float* d1, const float* d2, int write_x,
+                           const float* g, const float* b, uint16_t* planes, float* y32, int rows, int d, hipStream_t stream);
+// fp32 [rows, ld_in] (K columns) -> planes [rows, 2 * Kp] zero padded; gelu != 0: QuickGELU first
+hipError_t launch_rows_split(const float* x, int64_t ld_in, uint16_t* out, int64_t rows, int K, int Kp, int gelu, hipStream_t stream);
+// qkv fp32 [rows, 3 * width] -> attention output planes [rows, 2 * width]; ragged / prefix-sharing as launch_attention
+hipError_t launch_attention_split(const float* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len, int heads,
+                                  int causal, hipStream_t stream, const int32_t* pfx = nullptr);
 
 // ---- sd_ops.hip / sd_attention.hip: latent-diffusion reference generator (bf16 token-major activations)
 hipError_t sd_im2col3x3(const uint16_t* in, uint16_t* out, int n, int Hi, int Wi, int C, int stride, int up, hipStream_t st);

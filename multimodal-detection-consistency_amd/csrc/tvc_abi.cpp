@@ -9,6 +9,11 @@ int tvc_precise_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, flo
 int tvc_precise_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, int32_t normalize,
                             float* hidden_out, hipStream_t st);
 
+// tvc_split.cpp
+int tvc_split_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, hipStream_t st);
+int tvc_split_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, int32_t normalize, float* hidden_out,
+                          hipStream_t st);
+
 namespace {
 
 bool tower_ok(const tvc_tower_arch& a) {
@@ -217,6 +222,7 @@ int tvc_create(const tvc_model_desc* desc, const tvc_vision_weights* vision, con
 void tvc_destroy(tvc_handle* h) {
     if (!h) return;
     tvc_sd_free(h);
+    tvc_split_free(h);
     for (auto& b : h->ws) if (b.p) (void)hipFree(b.p);
     for (void* p : h->wT) if (p) (void)hipFree(p);
     for (auto& bk : h->banks) {
@@ -246,6 +252,7 @@ int tvc_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_
     const int chunk = B < h->max_chunk_images ? B : h->max_chunk_images;
     if (B == 0) return TVC_OK;
     if (h->tower_precision == 1) return tvc_precise_encode_image(h, pix_dev, B, out_dev, normalize, st);
+    if (h->tower_precision == 2) return tvc_split_encode_image(h, pix_dev, B, out_dev, normalize, st);
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * T, chunk, 0))) return rc;
     if ((rc = ensure(h, WS_PATCH, ((size_t)chunk * P + 512) * Kp * 2))) return rc;      // + tile padding, as ensure_tower_ws
@@ -296,6 +303,7 @@ int tvc_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* ou
     const int d = a.width, ctx = m.ctx;
     if (Tn == 0) return TVC_OK;
     if (h->tower_precision == 1) return tvc_precise_encode_text(h, tok_dev, Tn, out_dev, normalize, nullptr, st);
+    if (h->tower_precision == 2) return tvc_split_encode_text(h, tok_dev, Tn, out_dev, normalize, nullptr, st);
     int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
     // prefix sharing needs whole groups in a pass
     const int G = (h->pack_text && h->text_group >= 2 && Tn % h->text_group == 0) ? h->text_group : 0;
@@ -363,6 +371,7 @@ int tvc_encode_text_hidden(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, fl
     const int d = a.width, ctx = m.ctx;
     if (Tn == 0) return TVC_OK;
     if (h->tower_precision == 1) return tvc_precise_encode_text(h, tok_dev, Tn, nullptr, 0, out_dev, st);
+    if (h->tower_precision == 2) return tvc_split_encode_text(h, tok_dev, Tn, nullptr, 0, out_dev, st);
     const int chunk = Tn < h->max_chunk_texts ? Tn : h->max_chunk_texts;
     int rc;
     if ((rc = ensure_tower_ws(h, a, (int64_t)chunk * ctx, chunk, WS_TOWER_N))) return rc;
@@ -787,11 +796,17 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
         case TVC_OPT_TEXT_PACKING: h->pack_text = value != 0; return TVC_OK;
         case TVC_OPT_BANK_FILTER: h->bank_filter = value != 0; return TVC_OK;
         case TVC_OPT_POOLED_LAST_LAYER: h->pooled_last = value != 0; return TVC_OK;
-        case TVC_OPT_TOWER_PRECISION:
-            if (value != 0 && value != 1) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TOWER_PRECISION must be 0 (bf16) or 1 (fp32)");
-            if (value == 1 && !h->has_vision32 && !h->has_text32)
-                return fail(h, TVC_E_STATE, "tvc_set_option: TVC_OPT_TOWER_PRECISION = 1 needs tvc_set_weights_f32 first");
+        case TVC_OPT_TOWER_PRECISION: {
+            if (value < 0 || value > 2)
+                return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TOWER_PRECISION must be 0 (bf16), 1 (fp32) or 2 (split-bf16)");
+            if (value != 0 && !h->has_vision32 && !h->has_text32)
+                return fail(h, TVC_E_STATE, "tvc_set_option: TVC_OPT_TOWER_PRECISION = 1 / 2 needs tvc_set_weights_f32 first");
+            if (value == 2) {
+                const int rc = tvc_split_prepare(h);        // builds the weight planes once (synchronises the device)
+                if (rc) return rc;
+            }
             h->tower_precision = (int)value; return TVC_OK;
+        }
         case TVC_OPT_TEXT_GROUP:
             if (value < 0 || value > 4096) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_TEXT_GROUP out of range");
             h->text_group = (int)value; return TVC_OK;

@@ -133,6 +133,11 @@ extern "C" int tvc_set_weights_f32(tvc_handle* h, const tvc_vision_weights_f32* 
         h->tw32.layers = h->tlayers32.data();
         h->has_text32 = true;
     }
+    // the split-bf16 planes (TVC_OPT_TOWER_PRECISION = 2) are derived from these tensors: rebuild them when in use
+    if (vision || text) {
+        tvc_split_free(h);
+        if (h->tower_precision == 2) return tvc_split_prepare(h);
+    }
     return TVC_OK;
 }
 

@@ -54,8 +54,33 @@ struct Run {
     char* base = nullptr;
     size_t off = 0, high = 0;
     int rc = TVC_OK;
-    float* splitk = nullptr;          // fp32 partial tiles for the split-K form of GEMMs with fewer tiles than CUs
-    static constexpr size_t SPLITK_BYTES = (size_t)256 * 256 * 256 * 4;
+    // K split of a GEMM, chosen from the PER-SAMPLE shape only (never from the launch size): every sample's arithmetic is
+    // then the same whatever batch it is generated in, so an image is bit-for-bit independent of its batch mates and of the
+    // chunking of tvc_sd_generate (the reference's seed policy, src/sd_ref.py:389-412, promises reproducible references).
+    // Nominal batch: 8 samples (4 images x classifier-free guidance) -- the split that fills 256 CUs there; larger batches
+    // keep it (a little partial-tile traffic on deep-K launches), smaller ones run with fewer workgroups than CUs.
+    static constexpr int NOMINAL_SAMPLES = 8;
+    static int fixed_split(int I, int K, int planes, int64_t rows_per_sample) {
+        const int64_t tiles0 = (int64_t)((I + 255) / 256) * ((NOMINAL_SAMPLES * rows_per_sample + 255) / 256);
+        const int nk64 = (int)((int64_t)K * planes / 64);
+        int64_t S = tiles0 > 0 ? 256 / tiles0 : 1;
+        if (S > nk64 / 4) S = nk64 / 4;
+        if (S > 16) S = 16;
+        return S >= 2 ? (int)S : 1;
+    }
+    // launch with the fixed split; the fp32 partial tiles are scratch of the arena
+    void launch_fixed(GemmLaunch& g, int64_t rows_per_sample, const char* what) {
+        const int S = fixed_split(g.I, g.K, g.planes, rows_per_sample);
+        g.splitk_fixed = S;
+        const size_t mark = off;
+        if (S >= 2) {
+            const size_t tiles = (size_t)((g.I + 255) / 256) * (((size_t)g.J + 255) / 256);
+            g.splitk_ws_bytes = tiles * S * 256 * 256 * 4;
+            g.splitk_ws = (float*)alloc(g.splitk_ws_bytes);
+        }
+        if (live()) hip(timed_gemm(h, g, st), what);
+        off = mark;
+    }
 
     bool live() const { return rc == TVC_OK && !dry; }
     void hip(hipError_t e, const char* what) {
@@ -93,15 +118,15 @@ struct Run {
     bool has(const std::string& name) const { return S->w.count(name) != 0; }
 
     // out[j, i] = sum_k B[j, k] A[i, k] + bias[i]
-    void gemm(const void* A, int I, int K, const uint16_t* B, int64_t J, const float* bias, void* out, int64_t ldo, int epi) {
-        if (!live()) return;
+    // rows_per_sample: B rows of ONE sample (what the K split is chosen from)
+    void gemm(const void* A, int I, int K, const uint16_t* B, int64_t J, const float* bias, void* out, int64_t ldo, int epi,
+              int64_t rows_per_sample) {
         GemmLaunch g;
         g.A = (const uint16_t*)A; g.lda = K; g.I = I; g.B = B; g.ldb = K; g.J = (int)J; g.K = K;
         g.bias = bias; g.out = out; g.ldo = ldo; g.epilogue = epi; g.b_rows_padded = true;
         g.a_rows_padded = true;            // tvc_sd_load's contract: GEMM weights are readable to the next multiple of 256 rows
         // the 16 x 16 / 8 x 8 levels and the time / text projections are a few tiles with a long K: split it over the idle CUs
-        g.splitk_small = true; g.splitk_ws = splitk; g.splitk_ws_bytes = splitk ? SPLITK_BYTES : 0;
-        hip(timed_gemm(h, g, st), "sd gemm");
+        launch_fixed(g, rows_per_sample, "sd gemm");
     }
     // 3x3 convolution, stride 1, padding 1, as ONE GEMM of 9 K-planes: xp is in the padded layout with ZERO border rows
     // (a GroupNorm output), so tap (ky, kx) is the same token rows shifted by ky * (W + 2) + kx -- no im2col rows, the
@@ -120,17 +145,15 @@ struct Run {
         }
         const void* w = W(prefix + "weight");
         const float* b = (const float*)W(prefix + "bias");
-        if (!live()) return y;
         const int Wp = xp.W + 2;
         GemmLaunch g;
         g.A = (const uint16_t*)w; g.lda = 9 * (int64_t)xp.C; g.I = Cout; g.B = xp.p; g.ldb = xp.C;
         g.J = (int)(xp.rows() - 2 * (Wp + 1)); g.K = xp.C; g.planes = 9;
         for (int t = 0; t < 9; ++t) { g.a_plane_off[t] = t * xp.C; g.b_plane_off[t] = ((t / 3) * Wp + t % 3) * xp.C; }
         g.bias = b; g.ldo = Cout; g.b_rows_padded = true; g.a_rows_padded = true;
-        g.splitk_small = true; g.splitk_ws = splitk; g.splitk_ws_bytes = splitk ? SPLITK_BYTES : 0;
-        if (out_f32) { g.out = of + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_F32; }
-        else { g.out = y.p + (size_t)(Wp + 1) * Cout; g.epilogue = TVC_EPI_BF16; }
-        hip(timed_gemm(h, g, st), "sd conv gemm");
+        if (out_f32) { g.out = of ? of + (size_t)(Wp + 1) * Cout : nullptr; g.epilogue = TVC_EPI_F32; }
+        else { g.out = y.p ? y.p + (size_t)(Wp + 1) * Cout : nullptr; g.epilogue = TVC_EPI_BF16; }
+        launch_fixed(g, (int64_t)(xp.H + 2) * Wp, "sd conv gemm");
         return y;
     }
     // linear / 1x1 convolution on token rows
@@ -138,7 +161,7 @@ struct Run {
         Act y = act(x.n, x.H, x.W, Cout);
         const void* w = W(wname);
         const float* b = bname.empty() ? nullptr : (const float*)W(bname);
-        gemm(w, Cout, x.C, x.p, x.tok(), b, y.p, Cout, TVC_EPI_BF16);
+        gemm(w, Cout, x.C, x.p, x.tok(), b, y.p, Cout, TVC_EPI_BF16, (int64_t)x.H * x.W);
         return y;
     }
     // 3x3 convolution, padding 1: stride 1 / 2, or on the nearest-2x upsampling of x
@@ -172,7 +195,7 @@ struct Run {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)col.tok() * 9 * x.C * 4.0);      // rows written once, read once by the GEMM
             hip(sd_im2col3x3(x.p, col.p, x.n, x.H, x.W, x.C, stride, up, st), "sd_im2col3x3");
         }
-        gemm(w, Cout, 9 * x.C, col.p, col.tok(), b, y.p, Cout, TVC_EPI_BF16);
+        gemm(w, Cout, 9 * x.C, col.p, col.tok(), b, y.p, Cout, TVC_EPI_BF16, (int64_t)Ho * Wo);
         off = mark;
         return y;
     }
@@ -312,16 +335,18 @@ struct Run {
         // `pr` holds the probabilities [T (readable to Tp), T] -- and, before them, the image's compact V rows [T, C]
         uint16_t* pr = (uint16_t*)alloc(std::max((size_t)Tp * T, (size_t)T * C) * 2);
         if (T % 64 != 0 && rc == TVC_OK) rc = fail(h, TVC_E_INVALID, "tvc_sd: VAE attention needs H * W % 64 == 0");
-        for (int i = 0; i < n && live(); ++i) {
+        for (int i = 0; i < (dry ? 1 : n) && rc == TVC_OK; ++i) {          // (dry run: one image sizes the per-image scratch)
             const uint16_t* rows = qkv.p + (int64_t)i * T * 3 * C;
-            hip(hipMemcpy2DAsync(qc, (size_t)C * 2, rows, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy q");
-            hip(hipMemcpy2DAsync(kc, (size_t)C * 2, rows + C, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy k");
-            hip(hipMemcpy2DAsync(pr, (size_t)C * 2, rows + 2 * C, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy v");
-            hip(launch_transpose_bf16(pr, vT, T, C, st), "transpose v");
+            if (live()) {
+                hip(hipMemcpy2DAsync(qc, (size_t)C * 2, rows, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy q");
+                hip(hipMemcpy2DAsync(kc, (size_t)C * 2, rows + C, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy k");
+                hip(hipMemcpy2DAsync(pr, (size_t)C * 2, rows + 2 * C, (size_t)3 * C * 2, (size_t)C * 2, T, hipMemcpyDeviceToDevice, st), "copy v");
+                hip(launch_transpose_bf16(pr, vT, T, C, st), "transpose v");
+            }
             // scores[q, key] = q . k  (A = keys, B = queries), probabilities, out[q, c] = sum_key P[q, key] V^T[c, key]
-            gemm(kc, T, C, qc, T, nullptr, sc, T, TVC_EPI_F32);
-            hip(sd_softmax_rows(sc, pr, T, T, 1.0f / sqrtf((float)C), st), "sd_softmax_rows");
-            gemm(vT, C, T, pr, T, nullptr, a.p + (int64_t)i * T * C, C, TVC_EPI_BF16);
+            gemm(kc, T, C, qc, T, nullptr, sc, T, TVC_EPI_F32, T);
+            if (live()) hip(sd_softmax_rows(sc, pr, T, T, 1.0f / sqrtf((float)C), st), "sd_softmax_rows");
+            gemm(vT, C, T, pr, T, nullptr, a.p + (int64_t)i * T * C, C, TVC_EPI_BF16, T);
         }
         Act o = linear(a, p + "proj_attn.weight", p + "proj_attn.bias", C);
         if (live()) hip(sd_add_bf16(x.p, o.p, out.p, out.tok() * C, st), "sd_add");
@@ -350,11 +375,11 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
     const void* w1 = R.W("time_embedding.linear_1.weight"); const float* b1 = (const float*)R.W("time_embedding.linear_1.bias");
     const void* w2 = R.W("time_embedding.linear_2.weight"); const float* b2 = (const float*)R.W("time_embedding.linear_2.bias");
     if (R.live()) R.hip(sd_timestep_embed(te, n, c0, timestep, R.st), "timestep embed");
-    R.gemm(w1, Tdim, c0, te, n, b1, t1, Tdim, TVC_EPI_F32);
+    R.gemm(w1, Tdim, c0, te, n, b1, t1, Tdim, TVC_EPI_F32, 1);
     if (R.live()) R.hip(sd_cast_silu(t1, t1b, (int64_t)n * Tdim, 1, R.st), "silu");
-    R.gemm(w2, Tdim, Tdim, t1b, n, b2, t2, Tdim, TVC_EPI_F32);
+    R.gemm(w2, Tdim, Tdim, t1b, n, b2, t2, Tdim, TVC_EPI_F32, 1);
     if (R.live()) R.hip(sd_cast_silu(t2, t2b, (int64_t)n * Tdim, 1, R.st), "silu");       // resnets apply SiLU to temb first
-    R.gemm(S->temb_w, S->temb_total, Tdim, t2b, n, (const float*)S->temb_b, tadd, S->temb_total, TVC_EPI_F32);
+    R.gemm(S->temb_w, S->temb_total, Tdim, t2b, n, (const float*)S->temb_b, tadd, S->temb_total, TVC_EPI_F32, 1);
 
     // conv_in on the fp32 NCHW latents
     Act x = R.act(n, H, W, c0);
@@ -362,7 +387,8 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
         const size_t mark = R.off;
         uint16_t* col = (uint16_t*)R.alloc((size_t)pad_rows((int64_t)n * H * W) * 64 * 2);
         if (R.live()) R.hip(sd_im2col_in(latents, col, n, d.in_channels, H, W, 64, 1.0f, R.st), "im2col_in");
-        R.gemm(R.W("conv_in.weight"), c0, 64, col, (int64_t)n * H * W, (const float*)R.W("conv_in.bias"), x.p, c0, TVC_EPI_BF16);
+        R.gemm(R.W("conv_in.weight"), c0, 64, col, (int64_t)n * H * W, (const float*)R.W("conv_in.bias"), x.p, c0, TVC_EPI_BF16,
+               (int64_t)H * W);
         R.off = mark;
     }
     std::vector<Act> skips;
@@ -423,7 +449,7 @@ void vae_forward(Run& R, const float* latents, int n, int H, int W, float* image
         uint16_t* col = (uint16_t*)R.alloc((size_t)pad_rows((int64_t)n * H * W) * 64 * 2);
         if (R.live()) R.hip(sd_im2col_in(z, col, n, L, H, W, 64, 1.0f, R.st), "im2col_in");
         R.gemm(R.W("decoder.conv_in.weight"), top, 64, col, (int64_t)n * H * W, (const float*)R.W("decoder.conv_in.bias"), x.p, top,
-               TVC_EPI_BF16);
+               TVC_EPI_BF16, (int64_t)H * W);
         R.off = mark;
     }
     const float eps = 1e-6f;
@@ -446,14 +472,12 @@ void vae_forward(Run& R, const float* latents, int n, int H, int W, float* image
 template <class F>
 int with_arena(tvc_handle* h, hipStream_t st, Slot slot, F&& body) {
     Run dry{h, h->sd, st, true};
-    dry.splitk = (float*)dry.alloc(Run::SPLITK_BYTES);
     body(dry);
     if (dry.rc != TVC_OK) return dry.rc;
     int rc = ensure(h, slot, dry.high + 4096);
     if (rc) return rc;
     Run run{h, h->sd, st, false};
     run.base = (char*)h->ws[slot].p;
-    run.splitk = (float*)run.alloc(Run::SPLITK_BYTES);
     body(run);
     return run.rc;
 }
@@ -692,11 +716,10 @@ int tvc_sd_generate(tvc_handle* h, const float* cond_dev, const float* uncond_de
     // runs in chunks that keep the arena within TVC_OPT_SD_ARENA_BYTES.  A chunk is a whole sampling loop of its images
     // (every sample's arithmetic is independent of its batch mates), so chunking changes no image.
     Run dry{h, S, st, true};
-    dry.splitk = (float*)dry.alloc(Run::SPLITK_BYTES);
     unet_forward(dry, nullptr, 2, H, W, 0.f, nullptr, nullptr);
     if (dry.rc != TVC_OK) return dry.rc;
-    const size_t per_image = dry.high > Run::SPLITK_BYTES ? dry.high - Run::SPLITK_BYTES : dry.high;
-    int64_t chunk = (int64_t)((h->sd_arena_bytes > Run::SPLITK_BYTES ? h->sd_arena_bytes - Run::SPLITK_BYTES : 0) / (per_image ? per_image : 1));
+    const size_t per_image = dry.high;
+    int64_t chunk = (int64_t)(h->sd_arena_bytes / (per_image ? per_image : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     const size_t lat_per = (size_t)d.in_channels * H * W, ctx_per = (size_t)d.ctx * d.cross_attention_dim;
@@ -732,7 +755,7 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
                 uint16_t* tb = (uint16_t*)R.alloc((size_t)pad_rows(n) * Tdim * 2);
                 float* tadd = (float*)R.alloc((size_t)n * S->temb_total * 4);
                 if (R.live()) R.hip(sd_cast_silu(temb_dev, tb, (int64_t)n * Tdim, 1, R.st), "silu");
-                R.gemm(S->temb_w, S->temb_total, Tdim, tb, n, (const float*)S->temb_b, tadd, S->temb_total, TVC_EPI_F32);
+                R.gemm(S->temb_w, S->temb_total, Tdim, tb, n, (const float*)S->temb_b, tadd, S->temb_total, TVC_EPI_F32, 1);
                 tadd_all = tadd;
             }
             y = R.resnet(x, p, Cout, tadd_all, vae ? 1e-6f : d.norm_eps);

@@ -123,18 +123,30 @@ class TVCEngine:
                                                  C.byref(txt) if txt is not None else None))
         self._has_f32 = True
 
+    PRECISIONS = {"bf16": 0, "fp32": 1, "split": 2}
+
     def set_precision(self, precision: str) -> None:
-        """``"bf16"`` (default: bf16 MFMA towers, the benchmarked path) or ``"fp32"`` (fp32-grade towers: exact-f32
-        matrix instructions on the caller's fp32 weights -- embeddings within ~1e-6 of the reference's fp32 CPU path;
-        about 10x slower; validation / attack-generation mode)."""
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32' (got {precision!r})")
+        """Tower arithmetic (``TVC_OPT_TOWER_PRECISION``):
+
+        * ``"bf16"`` (default, the benchmarked path): bf16 x bf16 products, fp32 accumulation; scores within ~1e-3 of the
+          reference's fp32 CPU path;
+        * ``"split"``: fp32-grade at about a third of the bf16 matrix rate -- every activation and weight travels as
+          hi | lo bf16 planes, three MFMA products per element; scores within 1e-4 of the fp32 CPU path END TO END (the
+          bar of BASELINE.json), EOT packing / prefix sharing kept;
+        * ``"fp32"``: the exact reference -- every GEMM on the exact-f32 matrix instruction (1/16 of the bf16 rate),
+          fp32 attention; embeddings within ~1e-6 of the fp32 CPU path.
+
+        ``"split"`` and ``"fp32"`` upload fp32 copies of the caller's weights.  The input-gradient entry points
+        (``encode_image_grad`` / ``encode_image_backward``: the PGD / Hubness loops) ALWAYS run the bf16 path, whatever
+        this is set to."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)} (got {precision!r})")
         with self._lock, torch.cuda.device(self.device):
-            if precision == "fp32" and not self._has_f32:
+            if precision != "bf16" and not self._has_f32:
                 if self._w_host[0] is None and self._w_host[1] is None:
                     raise _lib.TVCError(_lib.TVC_E_STATE, "this engine has no towers to run in fp32")
                 self._upload_f32_weights()
-            self._check(self.lib.tvc_set_option(self.handle, _lib.TVC_OPT_TOWER_PRECISION, int(precision == "fp32")))
+            self._check(self.lib.tvc_set_option(self.handle, _lib.TVC_OPT_TOWER_PRECISION, self.PRECISIONS[precision]))
         self.precision = precision
 
     def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
@@ -562,6 +574,34 @@ class TVCEngine:
             self._check(self.lib.tvc_attention_f32(self.handle, _ptr(qkv), _ptr(out), n_seq, seq_len, heads, int(causal),
                                                    _stream()))
         return out
+
+    def gemm_split(self, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        """out [J, I] = x [J, K] w [I, K]^T + bias on hi | lo bf16 planes, three MFMA products per element (split-bf16 mode)."""
+        w = _require_cuda(w, torch.float32, "w")
+        x = _require_cuda(x, torch.float32, "x")
+        if w.shape[1] != x.shape[1]:
+            raise ValueError("w [I, K] and x [J, K] expected")
+        ld = (w.shape[0] + 3) // 4 * 4
+        out = torch.zeros((x.shape[0], ld), dtype=torch.float32, device=self.device)
+        if bias is not None:
+            bias = _require_cuda(bias, torch.float32, "bias")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_gemm_split(self.handle, _ptr(w), _ptr(x), _ptr(bias), _ptr(out), w.shape[0], x.shape[0],
+                                                w.shape[1], ld, _stream()))
+        return out[:, :w.shape[0]]
+
+    def attention_split(self, qkv: torch.Tensor, n_seq: int, seq_len: int, heads: int, causal: bool,
+                        starts: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 qkv rows -> fp32 attention output (hi + lo of the planes the split-bf16 tower's out-projection reads)."""
+        qkv = _require_cuda(qkv, torch.float32, "qkv")
+        w = heads * 64
+        planes = torch.zeros((qkv.shape[0], 2 * w), dtype=torch.bfloat16, device=self.device)
+        if starts is not None:
+            starts = _require_cuda(starts, torch.int32, "starts")
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.tvc_attention_split(self.handle, _ptr(qkv), _ptr(planes), _ptr(starts), n_seq, seq_len, heads,
+                                                     int(causal), _stream()))
+        return planes[:, :w].float() + planes[:, w:].float()
 
     def layernorm(self, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         x = _require_cuda(x, torch.float32, "x")

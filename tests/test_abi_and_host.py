@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(pkg._lib.SIGNATURES), declared ^ set(pkg._lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in tvc.h but not exported"
-    assert lib.tvc_abi_version() == pkg._lib.TVC_ABI_VERSION == 3
+    assert lib.tvc_abi_version() == pkg._lib.TVC_ABI_VERSION == 4
     out = subprocess.run(["nm", "-D", "--defined-only", str(pkg._lib.LIB_PATH)], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (tvc_[a-z0-9_]+)", out))
     assert declared <= exported

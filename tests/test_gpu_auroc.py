@@ -184,7 +184,7 @@ def test_auroc_three_method_defence_with_generated_sd_references_on_pgd_inputs(p
           f"|d sd_reference| max {d_sd.max():.2e} median {np.median(d_sd):.2e}; score spread (std) {ref.std():.3f}")
     assert abs(auc_gpu - auc_ref) <= 0.002
     assert abs(auc_sd_gpu - auc_sd_ref) <= 0.002
-    assert d_agg.max() < 4e-3 and d_sd.max() < 8e-3                 # ~2x measured
+    assert d_agg.max() < 1.2e-3 and d_sd.max() < 7e-4               # measured 5.5e-4 / 3.1e-4 (bf16 towers + bf16 UNet / VAE)
     flip = np.array([r["is_adversarial"] for r in res]) != np.array([r["is_adversarial"] for r in ref_res])
-    assert (np.abs(ref[flip] - 0.5) < 4e-3).all()
+    assert (np.abs(ref[flip] - 0.5) < 1.2e-3).all()
     clip.engine.close()

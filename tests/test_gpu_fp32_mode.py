@@ -1,6 +1,8 @@
-"""GPU: the fp32-grade tower mode (``TVC_OPT_TOWER_PRECISION = 1`` / ``TVCEngine(precision="fp32")``) -- the mode
-of the product in which BASELINE.json's "consistency scores match the reference CPU path within 1e-4 fp32" holds
-END TO END (towers included), not only on identical embeddings.
+"""GPU: the two fp32-grade tower modes -- ``TVCEngine(precision="fp32")`` (``TVC_OPT_TOWER_PRECISION = 1``: every GEMM on
+the exact-f32 matrix instruction, the exact reference, ~15x the bf16 step) and ``precision="split"`` (``= 2``, round 4:
+hi | lo bf16 planes, three MFMA products per element, ~3x the bf16 step) -- the modes of the product in which
+BASELINE.json's "consistency scores match the reference CPU path within 1e-4 fp32" holds END TO END (towers included),
+not only on identical embeddings.  Every end-to-end test below runs in BOTH modes against the same bounds.
 
 The reference's CPU path is fp32 throughout (/root/reference/src/detector.py:461-485;
 /root/reference/configs/attacks/pgd.yaml:80 asks for fp32).  The oracle is ``oracle/clip_oracle.py`` (PyTorch fp32 on
@@ -64,16 +66,64 @@ def test_attention_f32_vs_fp64(pkg, n_seq, T, heads, causal):
     eng.close()
 
 
-def test_fp32_mode_needs_fp32_weights_and_switches_back(pkg):
+@pytest.mark.parametrize("I,J,K", [(128, 128, 64), (200, 333, 588), (3072, 257, 1024), (1024, 1000, 4096), (768, 7, 768), (320, 2000, 128)])
+def test_gemm_split_vs_fp64(pkg, I, J, K):
+    """Three bf16 MFMA products per element on hi | lo planes: |err| ~ 2^-17 per operand, i.e. ~1e-5 * sqrt(K) * E|x w| at
+    worst -- measured against fp64 on unit-variance operands (ragged shapes: rows / columns padded inside the call)."""
+    eng = pkg.TVCEngine()
+    g = torch.Generator().manual_seed(I + J + K)
+    w, x, bias = torch.randn((I, K), generator=g), torch.randn((J, K), generator=g), torch.randn((I,), generator=g)
+    ref = x.double() @ w.double().t() + bias.double()
+    out = eng.gemm_split(w.cuda(), x.cuda(), bias.cuda()).cpu()
+    err = (out.double() - ref).abs().max().item()
+    e16 = (x.bfloat16().double() @ w.bfloat16().double().t() + bias.double() - ref).abs().max().item()
+    print(f"[measured] split GEMM I={I} J={J} K={K}: max |err| {err:.2e} (one bf16 product: {e16:.2e}); |out| ~ {ref.abs().mean():.1f}")
+    assert err < 4e-6 * K ** 0.5 * 4 and err < e16 / 50
+    eng.close()
+
+
+@pytest.mark.parametrize("n_seq,T,heads,causal", [(3, 257, 4, False), (5, 77, 2, True), (2, 50, 12, False), (1, 1, 1, True),
+                                                  (40, 17, 4, False), (3, 288, 2, True)])
+def test_attention_split_vs_fp64(pkg, n_seq, T, heads, causal):
+    eng = pkg.TVCEngine()
+    g = torch.Generator().manual_seed(T)
+    d = heads * 64
+    qkv = torch.randn((n_seq * T, 3 * d), generator=g)
+    out = eng.attention_split(qkv.cuda(), n_seq, T, heads, causal).cpu()
+    q, k, v = qkv.double().view(n_seq, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * T, d)
+    err = (out.double() - ref).abs().max().item()
+    print(f"[measured] split attention n_seq={n_seq} T={T} heads={heads} causal={causal}: max |err| {err:.2e}")
+    assert err < 2e-5
+    # ragged (packed) sequences: the same rows as two launches' worth of different lengths
+    if T >= 50 and not causal:
+        lens = [T, T - 13, 7][:n_seq]
+        starts = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+        rows = int(starts[-1])
+        got = eng.attention_split(qkv[:rows].cuda(), len(lens), T, heads, False, starts=starts.cuda()).cpu()
+        for i, L in enumerate(lens):
+            blk = qkv[int(starts[i]):int(starts[i]) + L].double().view(L, 3, heads, 64).permute(1, 2, 0, 3)
+            r = ((blk[0] @ blk[1].transpose(-1, -2) * 0.125).softmax(-1) @ blk[2]).permute(1, 0, 2).reshape(L, d)
+            assert (got[int(starts[i]):int(starts[i]) + L].double() - r).abs().max().item() < 2e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_fp32_mode_needs_fp32_weights_and_switches_back(pkg, precision):
     arch = pkg.get_arch("ViT-T/16-test")
     vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
     eng = pkg.TVCEngine(arch, vw, tw)
     imgs = pkg.synth.make_images(3, arch.image_size, seed=1).cuda()
     toks = pkg.synth.make_tokens(2, 3, arch.ctx, seed=2).view(-1, arch.ctx).cuda()
     with pytest.raises(pkg.TVCError):                      # the C-ABI refuses the mode before tvc_set_weights_f32
-        eng.set_option(pkg._lib.TVC_OPT_TOWER_PRECISION, 1)
+        eng.set_option(pkg._lib.TVC_OPT_TOWER_PRECISION, eng.PRECISIONS[precision])
+    with pytest.raises(pkg.TVCError):
+        eng.set_option(pkg._lib.TVC_OPT_TOWER_PRECISION, 3)
     a16, t16 = eng.encode_image(imgs), eng.encode_text(toks)
-    eng.set_precision("fp32")
+    eng.set_precision(precision)
     a32, t32, h32 = eng.encode_image(imgs), eng.encode_text(toks), eng.encode_text_hidden(toks)
     with torch.no_grad():
         ri = clip_oracle.vision_forward(vw, imgs.cpu(), arch.vision.heads, arch.patch)
@@ -81,7 +131,10 @@ def test_fp32_mode_needs_fp32_weights_and_switches_back(pkg):
         rh = clip_oracle.text_hidden(tw, toks.cpu().long(), arch.text.heads)
     (ci, di), (ct, dt) = _dev(a32.cpu(), ri), _dev(t32.cpu(), rt)
     dh = (h32.cpu() - rh).abs().max().item()
-    print(f"[measured] fp32 mode, ViT-T/16-test: image max|d| {di:.2e}  text max|d| {dt:.2e}  hidden max|d| {dh:.2e}")
+    print(f"[measured] {precision} mode, ViT-T/16-test: image max|d| {di:.2e}  text max|d| {dt:.2e}  hidden max|d| {dh:.2e}")
+    # grouped texts (original + variants: EOT packing + prefix sharing in the split mode, dense rows in the fp32 mode)
+    tg = eng.encode_text(toks, group=4)
+    assert (tg.cpu() - rt).abs().max().item() < EMB_BOUND
     assert di < EMB_BOUND and dt < EMB_BOUND and dh < 2e-4
     # un-normalised outputs too
     with torch.no_grad():
@@ -94,11 +147,12 @@ def test_fp32_mode_needs_fp32_weights_and_switches_back(pkg):
     eng.close()
 
 
-def test_fp32_mode_config0_end_to_end_within_1e4(pkg):
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_fp32_mode_config0_end_to_end_within_1e4(pkg, precision):
     """BASELINE configs[0] exactly: ViT-B/32, batch 8, N = 4, 1 k-row bank; every query."""
     arch = pkg.get_arch("ViT-B/32")
     vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
-    eng = pkg.TVCEngine(arch, vw, tw, precision="fp32")
+    eng = pkg.TVCEngine(arch, vw, tw, precision=precision)
     B, N, R = 8, 4, 1000
     images = pkg.synth.make_images(B, arch.image_size, seed=1)
     tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2)
@@ -118,7 +172,7 @@ def test_fp32_mode_config0_end_to_end_within_1e4(pkg):
     errs = {key: float(np.abs(rec[:, col] - ref[key]).max())
             for col, key in ((0, "original_similarity"), (1, "variant_mean"), (2, "variant_std"), (5, "score_src"),
                              (6, "retrieval_consistency"), (7, "retrieval_std"), (10, "overall_exp"))}
-    print(f"[measured] fp32 mode, configs[0] end to end vs the fp32 CPU path: image min cos {ci:.7f} max|d| {di:.2e}; "
+    print(f"[measured] {precision} mode, configs[0] end to end vs the fp32 CPU path: image min cos {ci:.7f} max|d| {di:.2e}; "
           f"text min cos {ct:.7f} max|d| {dt:.2e}; " + "  ".join(f"|d {k}| {v:.2e}" for k, v in errs.items()))
     assert di < EMB_BOUND and dt < EMB_BOUND
     for k, v in errs.items():
@@ -129,12 +183,13 @@ def test_fp32_mode_config0_end_to_end_within_1e4(pkg):
     eng.close()
 
 
-def test_fp32_mode_config2_step_8_queries_within_1e4(pkg):
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_fp32_mode_config2_step_8_queries_within_1e4(pkg, precision):
     """The configs[2] step (ViT-L/14, B = 512, N = 8, 1 M-row bf16 bank) with fp32-grade towers; 8 of its queries
     against the fp32 CPU towers + reference arithmetic."""
     arch = pkg.get_arch("ViT-L/14")
     vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
-    eng = pkg.TVCEngine(arch, vw, tw, precision="fp32")
+    eng = pkg.TVCEngine(arch, vw, tw, precision=precision)
     B, N, R, D = 512, 8, 1_000_000, arch.embed_dim
     images = pkg.synth.make_images(B, arch.image_size, seed=1).cuda()
     tokens = pkg.synth.make_tokens(B, N, arch.ctx, seed=2).cuda()
@@ -162,7 +217,7 @@ def test_fp32_mode_config2_step_8_queries_within_1e4(pkg):
     errs = {key: float(np.abs(rec[sub, col] - ref[key]).max())
             for col, key in ((0, "original_similarity"), (1, "variant_mean"), (2, "variant_std"), (5, "score_src"),
                              (6, "retrieval_consistency"), (10, "overall_exp"))}
-    print(f"[measured] fp32 mode, configs[2] step (8 of 512 queries) vs the fp32 CPU path: image min cos {ci:.7f} max|d| {di:.2e}; "
+    print(f"[measured] {precision} mode, configs[2] step (8 of 512 queries) vs the fp32 CPU path: image min cos {ci:.7f} max|d| {di:.2e}; "
           f"text min cos {ct:.7f} max|d| {dt:.2e}; " + "  ".join(f"|d {k}| {v:.2e}" for k, v in errs.items()))
     assert di < EMB_BOUND and dt < EMB_BOUND
     for k_, v in errs.items():

@@ -75,6 +75,7 @@ def parse(argv=None):
     p.add_argument("--no-live-traffic", action="store_true",
                    help="do not measure roofline.traffic live (two rocprofv3 --pmc child passes of this command with --steps 1, "
                         "run BEFORE this process touches the GPU; the default N=1 run does, ~1.5 min); fall back to the committed profile")
+    p.add_argument("--no-parity-modes", action="store_true", help="skip the parity_mode extra (the step in the split-bf16 and fp32 tower modes)")
     p.add_argument("--master-port", type=int, default=0)
     p.add_argument("--dry-run-launch", action="store_true",
                    help="launch-contract rehearsal WITHOUT a GPU (CPU test of the --gpus N launcher): the ranks form a "
@@ -180,7 +181,7 @@ def host_cpus() -> int:
 
 
 # --------------------------------------------------------------------------- CPU baselines (oracle = checker / timed port)
-def cpu_baseline(arch, weights, images, tokens, bank_cpu, budget_s, threads, schedule="dedup", max_queries=None):
+def cpu_baseline(arch, weights, images, tokens, bank_cpu, budget_s, threads, schedule="dedup", max_queries=None, scores_out=None):
     """The oracle (CPU restatement of the reference path, PyTorch-CPU fp32 towers + numpy scores) timed on
     this box's host cores on a bounded sample of the same workload.
     schedule "dedup": image encoded once per query, the N+1 texts in one batch (the de-duplicated minimum);
@@ -211,7 +212,9 @@ def cpu_baseline(arch, weights, images, tokens, bank_cpu, budget_s, threads, sch
     done = 0
     limit = images.shape[0] if max_queries is None else min(max_queries, images.shape[0])
     while done < limit:
-        one(done)
+        r = one(done)
+        if scores_out is not None:          # the oracle's scores of query `done` (parity_mode: deviation of each tower mode)
+            scores_out.append({k: float(r[k][0]) for k in ("original_similarity", "score_src", "overall_exp")})
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
@@ -468,13 +471,19 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_ring4_kernel<EPI> (all tvc GEMM launches of a step: the persistent ring kernels + the few small gemm_bf16_kernel ones)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4),
                 "traffic": None, "launches_per_step": g["launches"],
-                "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
+                "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4),
+                # the denominator of `traffic`: COMPULSORY HBM bytes per launch (every distinct operand plane read once, the
+                # output written once) of the same launches -- the GEMM launches of >= 64 tiles, i.e. the ring kernels
+                "traffic_algorithmic": round(g["big_bytes"] / max(g["big_launches"], 1) / 1e9, 3),
+                "ring_launches_per_step": g["big_launches"]}
 
     if roof is not None and rank == 0 and live_traffic:
         ring = [(v["launches"], v["hbm_MB_per_launch"]) for kk, v in live_traffic.items() if kk.startswith("gemm_ring")]
         if ring:
             roof["traffic"] = round(sum(n * mb for n, mb in ring) / sum(n for n, _ in ring) / 1e3, 3)
             roof["traffic_unit"] = "GB per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, launch-weighted mean over the ring GEMMs)"
+            if roof.get("traffic_algorithmic"):
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["traffic_algorithmic"], 2)
             roof["traffic_source"] = (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only) of this command with "
                                       f"--steps 1, run by bench.py as child processes before the timed run ({live_traffic.get('_seconds')} s)")
             roof["traffic_by_kernel_GB"] = {kk: round(v["hbm_MB_per_launch"] / 1e3, 3) for kk, v in live_traffic.items()
@@ -568,6 +577,20 @@ def main():
         out["pipelined"] = {"qps": round(B * ks / d_pl, 2), "ms_per_step": round(d_pl / ks * 1e3, 3),
                             "note": "the same step software-pipelined: batch i + 1's towers enqueued before batch i's bank "
                                     "search / consistency (one batch retired per step, records bit-identical); not `value`"}
+    rec_modes = {"bf16": rec}
+    if extras and not a.no_parity_modes:
+        # ---- the two fp32-grade tower modes on the SAME step (BASELINE.json: scores within 1e-4 of the reference's fp32 CPU
+        # path): "split" = hi | lo bf16 planes, three MFMA products (TVC_OPT_TOWER_PRECISION = 2); "fp32" = the exact-f32
+        # matrix instruction (= 1).  Their deviation from the CPU oracle is filled in below, from the queries the
+        # cpu_baseline leg runs anyway.  Never `value`.
+        out["parity_mode"] = {}
+        for mode, ks in (("split", 3), ("fp32", 1)):
+            eng.set_precision(mode)
+            d_m, (rec_m, _) = timed(lambda: step(serial=False), ks, 1)
+            rec_modes[mode] = rec_m
+            out["parity_mode"][mode] = {"tower_precision_option": eng.PRECISIONS[mode], "qps": round(B * ks / d_m, 2),
+                                        "ms_per_step": round(d_m / ks * 1e3, 2), "vs_bf16_step": round(d_m / ks / (dt / a.steps), 2)}
+        eng.set_precision("bf16")
     if extras:
         # ---- the same workload through the API the reference's runners call: strings + image tensors in,
         # Python result objects out (experiments/runners/run_detection.py:164-203, run_ablation.py:308-312)
@@ -593,6 +616,40 @@ def main():
                     "retrieval (B texts re-encoded + top-5 of the 1M-row index) + detection (src polarity, no bank); "
                     "defense.batch_detect = encode + bank search of the B*(N+1) text rows + consistency + the stateful "
                     "host-side ConsistencyChecker"}
+        # one query at a time, as the reference's own callers do (src/pipeline.py:284-288 -> process_single): latency
+        lat = []
+        for i in range(6):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            pipe.process_single(images[i], texts[i])
+            torch.cuda.synchronize(); lat.append(time.perf_counter() - t1)
+        out["through_api"]["process_single_ms"] = round(sorted(lat[1:])[len(lat[1:]) // 2] * 1e3, 2)
+        out["through_api"]["process_single_note"] = ("median of 5 calls, one query end to end (text variants + retrieval over the "
+                                                     f"{R}-row index + detection); the reference's README quotes ~50 ms per query for "
+                                                     "its CLIP-only path on its own hardware (README.md:896, context only)")
+
+    if extras:
+        # ---- K5 in the HBM-bound regime of SURVEY.md 8(d): small query batches (the reference searches one query at a time,
+        # src/retrieval.py:636-680; configs[0] has 48 rows).  GB/s = R * D * 2 B / t of the whole search (sample pre-pass,
+        # filter, select), against the ~6.3 TB/s a streaming kernel reaches on this chip.
+        sm = {}
+        qrows = torch.nn.functional.normalize(torch.randn((256, D), device=dev, generator=torch.Generator(device=dev).manual_seed(5)), dim=-1)
+        for Ms in (1, 10, 48, 256):
+            q = qrows[:Ms].contiguous()
+            for _ in range(3):
+                eng.bank_search(q, k, cfg.similarity_threshold, want_moments=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                eng.bank_search(q, k, cfg.similarity_threshold, want_moments=False)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            sm[f"M={Ms}"] = {"ms": round(ms, 3), "GBps": round(bank.shape[0] * D * 2 / ms / 1e6, 1),
+                             "frac_of_6.3TBps": round(bank.shape[0] * D * 2 / ms / 1e6 / 6300, 3)}
+        eng.bank_status()
+        sm["note"] = (f"exact top-{k} of M query rows over the {bank.shape[0]}-row bf16 bank, whole search per call; M <= 64 takes the "
+                      "skinny filter (bank.hip: bank_filter_skinny_kernel), larger batches the 256-query-tile ring kernel")
+        out["bank_stage_small_m"] = sm
 
     if extras and not a.serial_towers:
         # ---- the same step when the caller holds HOST buffers (pinned): H2D of the 512 images (308 MB fp32) and the
@@ -750,7 +807,22 @@ def main():
         cores = host_cpus()             # more threads than the cgroup quota only thrash
         bank_cpu = bank.float().cpu().numpy()
         img_c, tok_c = images[:nq].cpu(), tokens[:nq].cpu().long()
-        v, done, secs = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, a.cpu_seconds, cores)
+        oracle_scores = []
+        v, done, secs = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, a.cpu_seconds, cores, scores_out=oracle_scores)
+        if oracle_scores:
+            # END-TO-END deviation of every tower mode's records from the fp32 CPU path, on the queries just timed
+            cols = {"original_similarity": 0, "score_src": 5, "overall_exp": 10}
+            devs = {}
+            for mode, r_m in rec_modes.items():
+                devs[mode] = {k: max(abs(float(r_m[i, c]) - o[k]) for i, o in enumerate(oracle_scores)) for k, c in cols.items()}
+            if "parity_mode" in out:
+                for mode in out["parity_mode"]:
+                    out["parity_mode"][mode]["max_abs_score_dev"] = {k: float(f"{x:.3g}") for k, x in devs[mode].items()}
+                out["parity_mode"]["bf16_default"] = {"max_abs_score_dev": {k: float(f"{x:.3g}") for k, x in devs["bf16"].items()}}
+                out["parity_mode"]["note"] = (f"|record - fp32 CPU oracle| over the {len(oracle_scores)} queries of the cpu_baseline sample, "
+                                              "END TO END (towers included); bar of BASELINE.json: 1e-4")
+            else:
+                out["score_dev_vs_cpu_oracle"] = {k: float(f"{x:.3g}") for k, x in devs["bf16"].items()}
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": cores, "kind": "port",
                                "sample": f"{done} queries of the same workload in {secs:.1f}s, oracle "
                                          f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}

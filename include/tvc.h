@@ -386,9 +386,12 @@ enum { TVC_PROF_GEMM = 0, TVC_PROF_ATTENTION = 1, TVC_PROF_BANK = 2, TVC_PROF_RO
  * a pair of hipEvents on its stream.  tvc_profile_end synchronises, then fills
  * per category (index = TVC_PROF_*): ms[c] = summed kernel time, work[c] =
  * summed algorithmic FLOPs (GEMM, attention, bank) or bytes (row ops),
- * launches[c] = number of launches; profiling is switched off again. */
+ * launches[c] = number of launches; profiling is switched off again.  big_gemm (double[3], may be NULL): over the GEMM
+ * launches of >= 64 output tiles (the persistent ring kernels, the `roofline` kernel of bench.py) -- [0] their summed
+ * COMPULSORY HBM bytes (every distinct operand plane read once, the output written once), [1] their count, [2] their ms:
+ * the denominator that roofline.traffic (PMC bytes per launch) is compared with. */
 int tvc_profile_begin(tvc_handle* h);
-int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches);
+int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches, double* big_gemm);
 
 /* ---- building blocks exported for parity tests and profiling --------- */
 

@@ -106,7 +106,7 @@ SIGNATURES = {
     "tvc_consistency": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32,
                                   C.POINTER(ConsistencyParams), _P, _P]),
     "tvc_profile_begin": (C.c_int, [_P]),
-    "tvc_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tvc_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
     "tvc_gemm_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                 C.c_int32, _P]),
     "tvc_attention": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -421,6 +421,174 @@ __global__ __launch_bounds__(GEMM_THREADS) void bank_filter_ring_kernel(GemmOper
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// The filter pass for SMALL query batches (M <= 64: the reference searches ONE query at a time, src/retrieval.py:636-680;
+// BASELINE configs[0] has 48 rows) -- the HBM-bound regime of SURVEY.md 8(d).  The 256-query tile of the kernels above
+// multiplies 256 query columns whatever M is (R x 256 x D x 2 FLOP: 0.28 ms at R = 1 M even at the matrix peak) and
+// re-reads the bank through the L2 5 x; here the bank is streamed ONCE, straight from HBM into MFMA operand registers,
+// and multiplied with 16 * NQT query columns held in LDS:
+//   * a workgroup (8 waves, one per CU) owns a contiguous chunk of bank rows; each wave walks its own 16-row groups:
+//     all D / 64 x 2 sixteen-byte pieces of a group are requested before the previous group is multiplied (two register
+//     sets: ~50 KB of loads in flight per wave, 400 KB per CU -- latency is covered by bytes, not by occupancy);
+//   * a lane (row r = lane & 15, k-group g = lane >> 4) loads the 32 contiguous bytes [g * 32, g * 32 + 32) of every
+//     128-byte line of its row: the two MFMAs of a 64-deep block take k = 64 kb + 16 g + {0..7} and {8..15} -- any
+//     k permutation is a valid inner product as long as the query fragments use the same one (they do: the LDS image of
+//     the queries is read with the same offsets);
+//   * queries: hi planes [16 NQT, D] bf16 in LDS, row pitch D * 2 + 16 bytes (16 lanes of a ds_read_b128 group hit 16
+//     distinct 16-byte bank groups: conflict-free);
+//   * epilogue: as bank_tile_epilogue<FILTER> -- every lane compares its 4 rows x NQT queries with its queries' tau and
+//     appends survivors to the per-(chunk, query) lists (LDS slot counters, no global atomics).  The products are summed
+//     in another k order than in the ring kernel (fp32: ~1e-7), which the margin of kth_bound_kernel covers; the select
+//     pass re-scores the listed rows exactly, so the top-k set and values are the same.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KB, int NQT>
+__global__ __launch_bounds__(512) void bank_filter_skinny_kernel(const uint16_t* __restrict__ bank, int64_t ldb,
+                                                                  const uint16_t* __restrict__ qplanes, BankEpilogue e,
+                                                                  int rows_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = KB * 64;
+    constexpr int QPITCH = D * 2 + 16;
+    int* lds_cnt = (int*)(smem + NQT * 16 * QPITCH);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.x;
+    const int r16 = lane & 15, g = lane >> 4;
+    // ---- queries' hi planes -> LDS (rows >= M: zeros, tau = +inf below)
+    for (int idx = tid; idx < NQT * 16 * (D / 8); idx += 512) {
+        const int q = idx / (D / 8), c = idx - q * (D / 8);
+        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+        if (q < e.M) v = *(const u32x4_t*)(qplanes + (int64_t)q * 2 * D + c * 8);
+        *(u32x4_t*)(smem + q * QPITCH + c * 16) = v;
+    }
+    if (tid < NQT * 16) lds_cnt[tid] = 0;
+    float tau[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) {
+        const int q = n * 16 + r16;
+        tau[n] = (q < e.M) ? e.tau[q] : INFINITY;
+    }
+    __syncthreads();
+
+    const int64_t row_lo = (int64_t)chunk * rows_per_chunk;
+    int64_t row_hi = row_lo + rows_per_chunk;
+    if (row_hi > e.R) row_hi = e.R;
+    const int n_groups = row_hi > row_lo ? (int)((row_hi - row_lo + 15) >> 4) : 0;
+    const char* qbase = smem + r16 * QPITCH + g * 32;
+
+    auto load_group = [&](int grp, u32x4_t (&a)[2 * KB]) {
+        int64_t row = row_lo + (int64_t)grp * 16 + r16;
+        if (row >= e.R) row = e.R - 1;                        // clamped: masked in the epilogue
+        const uint16_t* src = bank + row * ldb + g * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            a[2 * kb] = __builtin_nontemporal_load((const u32x4_t*)(src + kb * 64));
+            a[2 * kb + 1] = __builtin_nontemporal_load((const u32x4_t*)(src + kb * 64 + 8));
+        }
+    };
+    auto compute_group = [&](int grp, const u32x4_t (&a)[2 * KB]) {
+        f32x4_t acc[NQT];
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, a[2 * kb + hf]);
+#pragma unroll
+                for (int n = 0; n < NQT; ++n) {
+                    const bf16x8_t bfr = *(const bf16x8_t*)(qbase + n * 16 * QPITCH + kb * 128 + hf * 16);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        const int64_t row0 = row_lo + (int64_t)grp * 16 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) {
+            const f32x4_t v = acc[n];
+            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (m4 > tau[n]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (v[r] > tau[n] && row0 + r < row_hi) {
+                        int q = n * 16 + r16;
+                        asm volatile("" : "+v"(q));
+                        if (q < e.M) {
+                            const int slot = atomicAdd(&lds_cnt[q], 1);
+                            if (slot < BANK_CAP) {
+                                Cand c;
+                                c.v = v[r];
+                                c.idx = (int32_t)(row0 + r + e.idx_offset);
+                                e.cand[((int64_t)chunk * e.M + q) * BANK_CAP + slot] = c;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // two register sets: group i + 8 is in flight while group i is multiplied
+    u32x4_t a0[2 * KB], a1[2 * KB];
+    int grp = wave;
+    if (grp < n_groups) load_group(grp, a0);
+    while (grp < n_groups) {
+        if (grp + 8 < n_groups) load_group(grp + 8, a1);
+        compute_group(grp, a0);
+        grp += 8;
+        if (grp >= n_groups) break;
+        if (grp + 8 < n_groups) load_group(grp + 8, a0);
+        compute_group(grp, a1);
+        grp += 8;
+    }
+    __syncthreads();
+    if (tid < NQT * 16 && tid < e.M) {
+        int c = lds_cnt[tid];
+        if (c > BANK_CAP) { c = BANK_CAP; atomicOr(e.overflow, 1); }
+        e.cand_cnt[(int64_t)chunk * e.M + tid] = c;
+    }
+}
+
+template <int KB>
+static hipError_t launch_skinny_kb(const uint16_t* bank, int64_t ldb, const uint16_t* qplanes, const BankEpilogue& e, int S,
+                                   int rows_per_chunk, hipStream_t stream) {
+    const int nqt = (e.M + 15) / 16;
+    const size_t lds = (size_t)nqt * 16 * (KB * 128 + 16) + 64 * 4 + 64;
+#define SKINNY_CASE(N)                                                                                                        \
+    case N: {                                                                                                                 \
+        static std::once_flag once;                                                                                           \
+        static hipError_t ast = hipSuccess;                                                                                   \
+        std::call_once(once, [] {                                                                                             \
+            ast = hipFuncSetAttribute((const void*)bank_filter_skinny_kernel<KB, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      4 * 16 * (KB * 128 + 16) + 64 * 4 + 64);                                                \
+        });                                                                                                                   \
+        if (ast != hipSuccess) return ast;                                                                                    \
+        hipLaunchKernelGGL((bank_filter_skinny_kernel<KB, N>), dim3(S), dim3(512), lds, stream, bank, ldb, qplanes, e,        \
+                           rows_per_chunk);                                                                                   \
+        break;                                                                                                                \
+    }
+    switch (nqt) {
+        SKINNY_CASE(1)
+        SKINNY_CASE(2)
+        SKINNY_CASE(3)
+        SKINNY_CASE(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef SKINNY_CASE
+    return hipGetLastError();
+}
+
+// D in {128, 512, 768} (two register sets of D / 64 x 2 sixteen-byte pieces: D = 1024 would spill) and M <= 64; false = shape
+// not covered (the caller takes the 256-query-tile kernels)
+static bool skinny_covers(int D, int M) { return M >= 1 && M <= 64 && (D == 128 || D == 512 || D == 768); }
+static hipError_t launch_bank_filter_skinny(const uint16_t* bank, int64_t ldb, int D, const uint16_t* qplanes, const BankEpilogue& e,
+                                            int S, int rows_per_chunk, hipStream_t stream) {
+    switch (D) {
+        case 128: return launch_skinny_kb<2>(bank, ldb, qplanes, e, S, rows_per_chunk, stream);
+        case 512: return launch_skinny_kb<8>(bank, ldb, qplanes, e, S, rows_per_chunk, stream);
+        case 768: return launch_skinny_kb<12>(bank, ldb, qplanes, e, S, rows_per_chunk, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // (v desc, idx asc) ordering
 __device__ __forceinline__ bool cand_better(float v, int idx, float ov, int oidx) {
     return (v > ov) || (v == ov && idx < oidx);
@@ -716,7 +884,12 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     // the one-tile-at-a-time loop, for A/B runs); the ragged last bank tile is handled inside the kernel
     static const bool ring_on = [] { const char* v = getenv("TVC_BANK_RING"); return !v || atoi(v) != 0; }();
     const bool ring = filter && ring_on && L.q_rows_padded && (g.lda % 64 == 0) && (g.ldb % 64 == 0) && L.R >= GEMM_BM;
-    if (ring)
+    // small query batches: the bank streamed once from HBM against <= 64 query columns (TVC_BANK_SKINNY=0: off, for A/B runs)
+    static const bool skinny_on = [] { const char* v = getenv("TVC_BANK_SKINNY"); return !v || atoi(v) != 0; }();
+    if (filter && skinny_on && skinny_covers(D, L.M) && L.ldb % 8 == 0) {
+        st = launch_bank_filter_skinny(L.bank, L.ldb, D, L.qplanes, e, L.S, tpc * GEMM_BM, stream);
+        if (st != hipSuccess) return st;
+    } else if (ring)
         hipLaunchKernelGGL(bank_filter_ring_kernel, dim3(nQt * L.S), dim3(GEMM_THREADS), BANK_LDS_BYTES, stream,
                            g, e, nQt, L.S, tpc, nbt);
     else if (filter)

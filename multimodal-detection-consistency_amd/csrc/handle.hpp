@@ -57,6 +57,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int cat;
     double work;
+    double big_bytes = 0;     // GEMM launches of >= 64 output tiles (the persistent ring kernels): compulsory HBM bytes
 };
 
 struct tvc_handle {
@@ -152,8 +153,28 @@ struct ProfScope {
 
 inline double gemm_flops(const GemmLaunch& g) { return 2.0 * g.I * (double)g.J * g.K * g.planes; }
 
+// Compulsory HBM bytes of a GEMM launch: every distinct operand plane read once, the output written once (read once
+// more by the residual epilogue).  Planes that address the same rows shifted by whole rows (the nine taps of a 3 x 3
+// convolution on the token operand) count once.
+inline double gemm_compulsory_bytes(const GemmLaunch& g) {
+    auto distinct = [&](const int* off, int64_t ld) {
+        int n = 0;
+        for (int p = 0; p < g.planes; ++p) {
+            bool seen = false;
+            for (int q = 0; q < p; ++q) seen = seen || (off[p] % ld == off[q] % ld);
+            n += seen ? 0 : 1;
+        }
+        return n;
+    };
+    const double a = 2.0 * g.I * (double)g.K * distinct(g.a_plane_off, g.lda > 0 ? g.lda : g.K);
+    const double b = 2.0 * g.J * (double)g.K * distinct(g.b_plane_off, g.ldb > 0 ? g.ldb : g.K);
+    const double o = (double)g.I * g.J * (g.epilogue == TVC_EPI_F32 ? 4.0 : g.epilogue == TVC_EPI_RESID_F32 ? 8.0 : 2.0);
+    return a + b + o;
+}
+
 inline hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st, int splitk_slot = -1) {
     ProfScope ps(h, st, TVC_PROF_GEMM, gemm_flops(g));
+    if (ps.on && (int64_t)((g.I + 255) / 256) * ((g.J + 255) / 256) >= 64) ps.r.big_bytes = gemm_compulsory_bytes(g);
     if (splitk_slot >= 0 && h->ws[splitk_slot].p) {
         GemmLaunch g2 = g;
         g2.splitk_ws = (float*)h->ws[splitk_slot].p;

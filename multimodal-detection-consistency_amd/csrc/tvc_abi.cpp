@@ -831,16 +831,18 @@ int tvc_profile_begin(tvc_handle* h) {
     return TVC_OK;
 }
 
-int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches) {
+int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches, double* big_gemm) {
     if (!h) return TVC_E_INVALID;
     if (!ms || !work || !launches) return fail(h, TVC_E_INVALID, "tvc_profile_end: NULL output");
     h->prof = false;
     HIP_TRY(hipDeviceSynchronize());
     for (int c = 0; c < TVC_PROF_NCAT; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
+    if (big_gemm) big_gemm[0] = big_gemm[1] = big_gemm[2] = 0;
     for (auto& r : h->prof_recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cat >= 0 && r.cat < TVC_PROF_NCAT) {
             ms[r.cat] += t; work[r.cat] += r.work; launches[r.cat] += 1;
+            if (big_gemm && r.big_bytes > 0) { big_gemm[0] += r.big_bytes; big_gemm[1] += 1; big_gemm[2] += t; }
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }

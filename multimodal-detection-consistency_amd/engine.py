@@ -624,8 +624,12 @@ class TVCEngine:
         ms = (C.c_double * 4)()
         work = (C.c_double * 4)()
         n = (C.c_int64 * 4)()
-        self._check(self.lib.tvc_profile_end(self.handle, ms, work, n))
-        return {c: {"ms": ms[i], "work": work[i], "launches": int(n[i])} for i, c in enumerate(self.PROF_CATEGORIES)}
+        big = (C.c_double * 3)()
+        self._check(self.lib.tvc_profile_end(self.handle, ms, work, n, big))
+        out = {c: {"ms": ms[i], "work": work[i], "launches": int(n[i])} for i, c in enumerate(self.PROF_CATEGORIES)}
+        # the GEMM launches of >= 64 tiles (the ring kernels): compulsory HBM bytes, count, ms
+        out["gemm"].update({"big_bytes": big[0], "big_launches": int(big[1]), "big_ms": big[2]})
+        return out
 
     def set_option(self, option: int, value: int) -> None:
         """``_lib.TVC_OPT_*`` (e.g. text packing on / off)."""

@@ -98,6 +98,38 @@ def test_bank_search_filter_form(gpu_engine, pkg, R, M, D, k, dtype, scale):
             np.abs(np.diff(np.sort(S[m])[::-1][:k + 1])).min() < 2e-6 * scale
 
 
+@pytest.mark.parametrize("R,D,dtype", [(1, 128, torch.bfloat16), (17, 512, torch.bfloat16), (1000, 512, torch.bfloat16),
+                                       (70001, 768, torch.bfloat16), (300000, 768, torch.bfloat16), (4097, 128, torch.float32),
+                                       (50000, 768, torch.float32)])
+def test_bank_search_small_query_batches_skinny_form(gpu_engine, R, D, dtype):
+    """M <= 64 (the reference searches one query at a time, src/retrieval.py:636-680; configs[0]: 48 rows): the filter pass
+    streams the bank once against 16 / 32 / 48 / 64 query columns (bank.hip, bank_filter_skinny_kernel).  Exact against
+    fp64, and IDENTICAL (indices and re-scored values) to the same rows searched inside a 65-row batch, which takes the
+    256-query-tile kernels."""
+    k = 7
+    bank = _unit((R, D), 300 + R).to(dtype)
+    gpu_engine.set_bank(bank.cuda())
+    qall = _unit((65, D), 400 + D)
+    big_i, big_s, _ = gpu_engine.bank_search(qall.cuda(), k, want_moments=False)
+    gpu_engine.bank_status()
+    for M in (1, 10, 16, 17, 48, 64):
+        q = qall[:M]
+        idx, sim, _ = gpu_engine.bank_search(q.cuda(), k, want_moments=False)
+        gpu_engine.bank_status()
+        S = (q.double() @ bank.double().t()).numpy()
+        _check_topk(idx.cpu().numpy(), sim.cpu().numpy().astype(np.float64), S, k, 1e-5)
+        assert torch.equal(idx, big_i[:M]) and torch.equal(sim, big_s[:M]), (R, D, M)
+    # a NaN query row stays contained: never listed, the other rows unchanged (a NaN BANK row turns the filter's margin NaN,
+    # everything is listed, the status reports the overflow: test_bank_search_nan_rows_and_ragged_query_tile, 64 rows)
+    if R >= 1000:
+        qb = qall[:10].clone(); qb[3, 5] = float("nan")
+        i2, s2, _ = gpu_engine.bank_search(qb.cuda(), k, want_moments=False)
+        gpu_engine.bank_status()
+        assert (i2[3] == -1).all()
+        ok = [m for m in range(10) if m != 3]
+        assert torch.equal(i2[ok], big_i[ok]) and torch.equal(s2[ok], big_s[ok])
+
+
 def test_bank_search_ties_and_duplicates(gpu_engine):
     """Duplicate rows: equal similarities must come back ordered by index."""
     D = 128

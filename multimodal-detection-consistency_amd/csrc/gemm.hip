@@ -220,6 +220,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
 //     overlap; the epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
 //   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
 // ---------------------------------------------------------------------------
+#ifndef TVC_RING_F5
+#define TVC_RING_F5 0
+#endif
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,12 +339,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
 #define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
 #define RING4_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#if TVC_RING_F5
+    // ---- form 5 (experiment): every unit is issued ONE phase earlier (Aq0 of K-tile t+2 right after the
+    // phase that read Aq0 of K-tile t -- A rows are staged and read by the SAME wave group, so one phase is a safe
+    // write-after-read distance for them; the B units keep two) and there is ONE counted wait per K-tile, in p3:
+    // vmcnt(6) retires all four units of K-tile t+1 and leaves Aq0 / Bq0 / Bq1 of K-tile t+2 in flight (3..7 units in
+    // flight over a K-tile instead of 4..5) -- the wait placement of the guide's 256^2 8-phase template.
+    issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
+    issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    RING4_BARRIER()
+    if (wm == 1) RING4_BARRIER()
+#else
     // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
     issue_unit(U_A0{}); issue_unit(U_B0{});
     RING4_WAIT8()
     RING4_BARRIER()
     if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
+#endif
 
     // One K-tile.  CREDIT: the number of store instructions the previous tile's epilogue left behind the ring's loads in
     // this wave's (in-order) vector memory queue: the three counted waits of a tile's first K-tile let them pass
@@ -353,6 +369,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
 #define RING4_WAITC() { if (CREDIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
                         else if (CREDIT == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); \
                         else asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+#if TVC_RING_F5
+        // p0: read Aq0, Bq0 (t); stage Aq1 (t+1).  p1: read Bq1; stage Aq0 (t+2).  p2: read Aq1; stage Bq0 (t+2).
+        // p3: stage Bq1 (t+2); ONE wait: all of K-tile t+1 landed (the epilogue's stores of a tile's first K-tile are older
+        // than its Aq1 and drain with it: no store credit in this form).
+        issue_unit(U_A1{});
+        load_B(t, 0, B0f);
+        load_A(t, 0, A0f);
+        RING4_BARRIER()
+        RING4_MFMA(A0f, B0f, 0, 0)
+        RING4_BARRIER()
+        issue_unit(U_A0{});
+        load_B(t, 1, B1f);
+        RING4_BARRIER()
+        RING4_MFMA(A0f, B1f, 0, 1)
+        RING4_BARRIER()
+        issue_unit(U_B0{});
+        load_A(t, 1, A1f);
+        RING4_BARRIER()
+        RING4_MFMA(A1f, B1f, 1, 1)
+        RING4_BARRIER()
+        issue_unit(U_B1{});
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        RING4_BARRIER()
+        RING4_MFMA(A1f, B0f, 1, 0)
+        return;
+#endif
         // ===== p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
         issue_unit(U_B1{});
         load_B(t, 0, B0f);
@@ -399,12 +441,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     int t = 0;
 #pragma unroll 1
     for (ct = 0; ct < my_tiles; ++ct) {
+#if TVC_RING_F5 == 2
+        // two K-tiles per loop iteration: the LDS buffer of a K-tile is a compile-time constant (nkt even, so a tile starts on
+        // buffer 0); odd nkt takes the one-K-tile loop below
+        if ((nkt & 1) == 0) {
+            ktile(0, C0{}); RING4_BARRIER() ktile(1, C0{});
+#pragma unroll 1
+            for (int k = 2; k < nkt; k += 2) {
+                RING4_BARRIER()
+                ktile(0, C0{});
+                RING4_BARRIER()
+                ktile(1, C0{});
+            }
+            t += nkt;
+        } else
+#endif
+        {
         if (credit) ktile(t, CE{}); else ktile(t, C0{});
         ++t;
 #pragma unroll 1
         for (int k = 1; k < nkt; ++k, ++t) {
             RING4_BARRIER()
             ktile(t, C0{});
+        }
         }
         // the NEXT tile's bias slice goes into the queue ahead of this tile's stores: with it there, wave 0's credited
         // waits ask for one OLDER load more, never for a store

@@ -57,9 +57,12 @@ struct Run {
     // K split of a GEMM, chosen from the PER-SAMPLE shape only (never from the launch size): every sample's arithmetic is
     // then the same whatever batch it is generated in, so an image is bit-for-bit independent of its batch mates and of the
     // chunking of tvc_sd_generate (the reference's seed policy, src/sd_ref.py:389-412, promises reproducible references).
-    // Nominal batch: 8 samples (4 images x classifier-free guidance) -- the split that fills 256 CUs there; larger batches
-    // keep it (a little partial-tile traffic on deep-K launches), smaller ones run with fewer workgroups than CUs.
-    static constexpr int NOMINAL_SAMPLES = 8;
+    // Nominal batch: 24 samples (12 images x classifier-free guidance, the batch bench.py generates) -- K is split only
+    // where even that batch leaves most CUs without a tile (the 8 x 8 level, the time / text projections).  A split that
+    // filled the chip for a single image (S = 4 .. 16 at the 16 x 16 level) cost the 12-image batch 20 % of its GEMM time
+    // (r04_bench1: 602 against 497 ms) -- throughput of the batched generator is what configs[4] measures; one image alone
+    // runs its low-resolution levels on fewer workgroups than CUs.
+    static constexpr int NOMINAL_SAMPLES = 24;
     static int fixed_split(int I, int K, int planes, int64_t rows_per_sample) {
         const int64_t tiles0 = (int64_t)((I + 255) / 256) * ((NOMINAL_SAMPLES * rows_per_sample + 255) / 256);
         const int nk64 = (int)((int64_t)K * planes / 64);

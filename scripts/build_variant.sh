@@ -6,10 +6,10 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/multimodal-detection-consistency_amd/csrc
 out=$root/gpurun_abl; mkdir -p $out/obj_$name
-for f in gemm elementwise attention bank consistency backward attention_bwd precise sd_ops sd_attention; do
+for f in gemm elementwise attention bank consistency backward attention_bwd precise split sd_ops sd_attention; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
 done
-for f in tvc_abi tvc_precise tvc_sd; do
+for f in tvc_abi tvc_precise tvc_split tvc_sd; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip "$@" -c $src/$f.cpp -o $out/obj_$name/$f.o &
 done
 wait

@@ -131,6 +131,33 @@ def test_pipeline_surface(pkg, clip, images):
         pipe.process_batch(images, TEXTS[:2])
 
 
+def test_process_single_from_a_four_thread_pool(pkg, clip, images):
+    """The reference drives ``process_single`` from a ThreadPoolExecutor(max_workers=4) (src/pipeline.py:284-288,553-566).
+    One engine serves all four threads (a lock per entry point, every thread on its own current stream): 48 concurrent
+    calls -- retrieval over a shared image index, a defence detector with its own bank slot beside it -- return exactly what
+    the same calls return one after the other, and nothing deadlocks."""
+    from concurrent.futures import ThreadPoolExecutor
+    pc = pkg.PipelineConfig(enable_sd_reference=False,
+                            detector_config=pkg.DetectorConfig(clip_model="ViT-T/16-test", num_text_variants=3))
+    pipe = pkg.create_detection_pipeline(pc, clip_model=clip)
+    pipe.retriever.build_image_index(pkg.synth.make_images(64, 64, seed=9))
+    defense = pkg.MultiModalDefenseDetector(clip, config=pkg.DetectionConfig(text_variant_count=3, adaptive_threshold=False))
+    defense.set_reference_bank(torch.nn.functional.normalize(torch.randn((500, 128), generator=torch.Generator().manual_seed(2)), dim=-1).cuda())
+    jobs = [(i % 6, (i * 5) % 6) for i in range(48)]                      # (image, text) pairs, mismatched ones included
+
+    def one(job):
+        im, tx = job
+        r = pipe.process_single(images[im], TEXTS[tx])
+        d = defense.detect(images[im], TEXTS[tx])
+        return r.adversarial_score, tuple(r.retrieval_scores), r.is_adversarial, d["consistency_score"], d["is_adversarial"]
+
+    serial = [one(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        threaded = list(pool.map(one, jobs, timeout=300))
+    assert threaded == serial
+    assert len({s[0] for s in serial}) > 6                                 # the jobs really differ
+
+
 def test_reference_bank_matches_reference_golden(pkg, gpu_engine):
     """ReferenceBank.query_similar on the reference's own 20 x 512 fixture vs the
     outputs of the reference's own code (fp64 numpy); GPU path is split-bf16

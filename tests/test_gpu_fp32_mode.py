@@ -99,7 +99,9 @@ def test_attention_split_vs_fp64(pkg, n_seq, T, heads, causal):
     ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * T, d)
     err = (out.double() - ref).abs().max().item()
     print(f"[measured] split attention n_seq={n_seq} T={T} heads={heads} causal={causal}: max |err| {err:.2e}")
-    assert err < 2e-5
+    # unit-variance q, k, v: a logit is a 64-term sum of operands carried to ~2^-17 each (|err| ~ 1.5e-5 after the 1/8
+    # scale), so probabilities and outputs are good to ~2e-5 -- measured 0.8e-5 .. 2.3e-5; one bf16 product gives ~5e-3
+    assert err < 5e-5
     # ragged (packed) sequences: the same rows as two launches' worth of different lengths
     if T >= 50 and not causal:
         lens = [T, T - 13, 7][:n_seq]
@@ -109,7 +111,7 @@ def test_attention_split_vs_fp64(pkg, n_seq, T, heads, causal):
         for i, L in enumerate(lens):
             blk = qkv[int(starts[i]):int(starts[i]) + L].double().view(L, 3, heads, 64).permute(1, 2, 0, 3)
             r = ((blk[0] @ blk[1].transpose(-1, -2) * 0.125).softmax(-1) @ blk[2]).permute(1, 0, 2).reshape(L, d)
-            assert (got[int(starts[i]):int(starts[i]) + L].double() - r).abs().max().item() < 2e-5
+            assert (got[int(starts[i]):int(starts[i]) + L].double() - r).abs().max().item() < 5e-5
     eng.close()
 
 

@@ -184,7 +184,8 @@ const char* tvc_last_error(tvc_handle* h);
  * residual stream, LayerNorm, softmax and QuickGELU.  Scores within 1e-4 of the reference's fp32 CPU path END TO END at
  * about a third of the bf16 mode's matrix rate (mode 1: 1/16); EOT packing and prefix sharing are kept, the pooled last
  * layer is not.  Needs tvc_set_weights_f32 first; setting the option builds the weight planes (synchronises the device).
- * Geometry limits of modes 1 and 2: sequences of at most 288 tokens, head_dim 64 (as the bf16 towers).
+ * Geometry limits: head_dim 64 and sequences of at most 288 tokens in modes 0 and 1 (tvc_create refuses other towers),
+ * at most 272 tokens in mode 2 (TVC_E_INVALID when the option is set).
  * TVC_OPT_SD_ARENA_BYTES (default 48 GiB): budget of the activation arena of ONE UNet evaluation inside tvc_sd_generate.
  * The arena grows linearly with the samples of an evaluation (about 0.75 GB per image at 64 x 64 latents: both halves of
  * classifier-free guidance); a batch that would exceed the budget is generated in chunks of whole sampling loops -- every
@@ -509,9 +510,9 @@ int tvc_attention_f32(tvc_handle* h, const float* qkv_dev, float* out_dev, int32
 /* Building blocks of the split-bf16 tower mode (TVC_OPT_TOWER_PRECISION = 2), exported for parity tests:
  * tvc_gemm_split: out fp32 [J, ld_out] = x [J, K] w[I, K]^T + bias with both operands split into hi | lo bf16 planes and
  * three MFMA products per element (K % 4 == 0).
- * tvc_attention_split: qkv fp32 [rows, 3 * width] (head_dim 64, seq_len <= 288; starts_dev int32 [n_seq + 1] = packed
+ * tvc_attention_split: qkv fp32 [rows, 3 * width] (head_dim 64, seq_len <= 272; starts_dev int32 [n_seq + 1] = packed
  * sequences of at most seq_len rows, or NULL = n_seq x seq_len dense rows) -> the attention output as hi | lo bf16 planes
- * [rows, 2 * width] (value = hi + lo). */
+ * [rows, 2 * width] (value = hi + lo); seq_len <= 272. */
 int tvc_gemm_split(tvc_handle* h, const float* w_dev, const float* x_dev, const float* bias_dev, float* out_dev,
                    int32_t I, int32_t J, int32_t K, int32_t ld_out, void* stream);
 int tvc_attention_split(tvc_handle* h, const float* qkv_dev, uint16_t* out_planes_dev, const int32_t* starts_dev,

@@ -35,8 +35,6 @@
 #include <cstdlib>
 #include <mutex>
 
-#define BANK_CAP 128
-#define BANK_KEFF 16       // tau = max(k, 16)-th largest group maximum: a looser but far less noisy bound
 #define BANK_POOL 6144
 #define BANK_MAX_RESCORE_D 2048   // fp32 query row staged in LDS by the re-scoring select
 #define BANK_LDS_BYTES (GEMM_LDS_BYTES + 256 * 4 + 2 * 256 * 4 * 4)
@@ -46,49 +44,7 @@ struct Cand {
     int32_t idx;
 };
 
-void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap) {
-    const int64_t nbt = (R + GEMM_BM - 1) / GEMM_BM;
-    const int nqt = (M + GEMM_BN - 1) / GEMM_BN;
-    int64_t s = (1280 + nqt - 1) / nqt;
-    if (s > nbt) s = nbt;
-    if (s < 1) s = 1;
-    const int64_t tpc = (nbt + s - 1) / s;
-    s = (nbt + tpc - 1) / tpc;
-    // expected survivors per query ~ keff * R / n_sample (relative spread ~ keff^-1/2):
-    // aim at 8 per chunk list (cap 128) and at most ~2048 per query (select pool 6144)
-    const int keff = k > BANK_KEFF ? k : BANK_KEFF;
-    int64_t ns = (int64_t)keff * R / (8 * s);
-    // small query batches (the skinny filter, M <= 64): the select pass re-scores every survivor of a query in ONE workgroup
-    // (~2 us per 16 rows), so ~2 000 survivors cost 0.3-0.5 ms there -- more than streaming a 1 M-row bank; a 8 x larger
-    // sample (its GEMM is a few tens of microseconds at these M) leaves ~250
-    const int64_t ns2 = (int64_t)keff * R / (M <= 64 ? 256 : 2048);
-    if (ns < ns2) ns = ns2;
-    if (ns < 4096) ns = 4096;
-    // cap: the pre-pass similarities [M, ns] fp32 stay under 8 GiB (ns = 262144 at M = 5120 keeps a
-    // 10 M-row bank at ~600 survivors per query; the old 65536 cap left ~2800 +- 25 % and overflowed
-    // the 128-entry lists / 6144-entry pool for some of 5120 queries)
-    int64_t ns_cap = ((int64_t)8 << 30) / ((int64_t)(M > 0 ? M : 1) * 4);
-    if (ns_cap > 262144) ns_cap = 262144;
-    if (ns_cap < 65536) ns_cap = 65536;
-    if (ns > ns_cap) ns = ns_cap;
-    ns = (ns + 255) / 256 * 256;
-    if (ns > R) ns = R;
-    if (ns < 1) ns = 1;
-    // when the cap bites, keep the per-(chunk, query) lists short (<= ~24 expected, cap 128) by
-    // cutting the bank into more chunks instead
-    {
-        int64_t s_min = ((int64_t)keff * R + 24 * ns - 1) / (24 * ns);
-        if (s_min > nbt) s_min = nbt;
-        if (s < s_min) {
-            const int64_t tpc2 = (nbt + s_min - 1) / s_min;
-            s = (nbt + tpc2 - 1) / tpc2;
-        }
-    }
-    *n_sample = (int)ns;
-    *sample_stride = (int)(R / ns > 0 ? R / ns : 1);
-    *S = (int)s;
-    *cap = BANK_CAP;
-}
+// (bank_plan: host_plan.hpp)
 
 // tau[q] = (k-th largest of 256 group maxima of s0[q, :]) minus a safety margin
 // FILTER form: tau is lowered by the bound of what the one-product pass leaves out,

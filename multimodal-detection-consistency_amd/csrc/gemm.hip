@@ -220,8 +220,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
 //     overlap; the epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
 //   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
 // ---------------------------------------------------------------------------
+// TVC_RING_F5: 0 = form 4 (three counted waits per K-tile), 1 = form 5 (units one phase earlier, ONE counted wait per
+// K-tile), 2 = form 5 with two K-tiles per loop iteration (LDS buffer parity compile-time) -- the default since round 4:
+// bit-identical to form 4, +2.5-3.3 % on the four tower shapes and 1 355 against 1 250 TFLOP/s at 4096^3 in same-box A/B
+// (scripts/gemm_f5_ab.sh, gpurun_out/r04_f5_ab.log).
 #ifndef TVC_RING_F5
-#define TVC_RING_F5 0
+#define TVC_RING_F5 2
 #endif
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {

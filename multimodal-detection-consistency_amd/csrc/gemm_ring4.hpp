@@ -1,4 +1,4 @@
-// GEMM main loop, fourth form (barrier-staggered ping-pong in phases of 16 MFMAs over 64-deep whole-line K-tiles), as a
+// GEMM main loop, fourth / fifth form (barrier-staggered ping-pong in phases of 16 MFMAs over 64-deep whole-line K-tiles), as a
 // reusable stream: a workgroup multiplies a SEQUENCE of 256 x 256 output tiles, the LDS-DMA ring running across tile
 // boundaries.  The schedule, its hazards and its measurements are described at gemm_ring4_kernel (gemm.hip), which keeps
 // its own copy of this loop with the GEMM's tile-end extras (bias slices, store credit); this header serves the callers
@@ -131,38 +131,39 @@ __device__ __forceinline__ void ring4_stream(const GemmOperands& g, char* smem, 
     }
 #define RING4S_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 #define RING4S_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
+    // Form 5 (round 4; the schedule of gemm_ring4_kernel, gemm.hip): every unit is issued one phase earlier than in form 4
+    // (A units one phase after their only read -- staged and read by the same wave group --, B units two) and ONE counted wait
+    // per K-tile, in p3: vmcnt(6) retires all four units of K-tile t+1 and leaves Aq0 / Bq0 / Bq1 of K-tile t+2 in flight.
+    // ---- prologue: K-tile 0 whole, Aq0 / Bq0 / Bq1 of K-tile 1; K-tile 0 landed and published
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
-    issue_unit(U_A0{}); issue_unit(U_B0{});
-    RING4S_WAIT8()
+    issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     RING4S_BARRIER()
     if (wm == 1) RING4S_BARRIER()            // group 1 runs one barrier behind group 0 from here on
 
     auto ktile = [&](int t) __attribute__((always_inline)) {
-        // p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
-        issue_unit(U_B1{});
+        // p0: read Aq0, Bq0 of K-tile t; stage Aq1 of K-tile t+1
+        issue_unit(U_A1{});
         load_B(t, 0, B0f);
         load_A(t, 0, A0f);
-        RING4S_WAIT8()
         RING4S_BARRIER()
         RING4S_MFMA(A0f, B0f, 0, 0)
         RING4S_BARRIER()
-        // p1: read Bq1; stage Aq1 of K-tile t+1; Aq1 of K-tile t must have landed (read in p2)
-        issue_unit(U_A1{});
+        // p1: read Bq1; stage Aq0 of K-tile t+2
+        issue_unit(U_A0{});
         load_B(t, 1, B1f);
-        RING4S_WAIT8()
         RING4S_BARRIER()
         RING4S_MFMA(A0f, B1f, 0, 1)
         RING4S_BARRIER()
-        // p2: read Aq1; stage Aq0 of K-tile t+2
-        issue_unit(U_A0{});
+        // p2: read Aq1; stage Bq0 of K-tile t+2
+        issue_unit(U_B0{});
         load_A(t, 1, A1f);
         RING4S_BARRIER()
         RING4S_MFMA(A1f, B1f, 1, 1)
         RING4S_BARRIER()
-        // p3: stage Bq0 of K-tile t+2; Aq0, Bq0 of K-tile t+1 must have landed (read in the next p0)
-        issue_unit(U_B0{});
-        RING4S_WAIT8()
+        // p3: stage Bq1 of K-tile t+2; all of K-tile t+1 must have landed (read from the next p0 on)
+        issue_unit(U_B1{});
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         RING4S_BARRIER()
         RING4S_MFMA(A1f, B0f, 1, 0)
         // (the phase's second barrier is placed by the tile loop)
@@ -170,12 +171,25 @@ __device__ __forceinline__ void ring4_stream(const GemmOperands& g, char* smem, 
     int t = 0;
 #pragma unroll 1
     for (int ct = 0; ct < ntiles; ++ct) {
+        if ((nkt & 1) == 0) {
+            // two K-tiles per loop iteration: the LDS buffer of a K-tile is a compile-time constant (a tile starts on buffer 0)
+            ktile(0); RING4S_BARRIER() ktile(1);
+#pragma unroll 1
+            for (int k = 2; k < nkt; k += 2) {
+                RING4S_BARRIER()
+                ktile(0);
+                RING4S_BARRIER()
+                ktile(1);
+            }
+            t += nkt;
+        } else {
         ktile(t);
         ++t;
 #pragma unroll 1
         for (int k = 1; k < nkt; ++k, ++t) {
             RING4S_BARRIER()
             ktile(t);
+        }
         }
         if (wm == 1) tile_end(ct, acc);
         RING4S_BARRIER()

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "host_plan.hpp"
 
 enum { TVC_EPI_F32 = 0, TVC_EPI_BF16 = 1, TVC_EPI_GELU_BF16 = 2, TVC_EPI_RESID_F32 = 3 };
 
@@ -102,7 +103,6 @@ struct BankSearchLaunch {
     float* topk_sim = nullptr;
     float* moments = nullptr;
 };
-void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride, int* S, int* cap);
 hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream);
 hipError_t launch_bank_bounds(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R, float* bounds,
                               hipStream_t stream);
@@ -167,7 +167,6 @@ hipError_t launch_attention_split(const float* qkv, uint16_t* out, const int32_t
 // ---- sd_ops.hip / sd_attention.hip: latent-diffusion reference generator (bf16 token-major activations)
 hipError_t sd_im2col3x3(const uint16_t* in, uint16_t* out, int n, int Hi, int Wi, int C, int stride, int up, hipStream_t st);
 hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, int W, int Kp, float scale, hipStream_t st);
-size_t sd_groupnorm_ws_floats(int n, int HW, int groups);
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
                         int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,
                         hipStream_t st);

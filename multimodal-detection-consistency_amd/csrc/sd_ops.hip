@@ -548,16 +548,11 @@ hipError_t sd_im2col_in(const float* in, uint16_t* out, int n, int Cin, int H, i
 }
 
 // ws: >= n * nslab * groups * 2 + n * groups * 2 floats (sd_groupnorm_ws_floats)
-static int gn_slab_tokens(int HW);
-size_t sd_groupnorm_ws_floats(int n, int HW, int groups) {
-    const int slab = gn_slab_tokens(HW);
-    const int nslab = (HW + slab - 1) / slab;
-    return (size_t)n * nslab * groups * 2 + (size_t)n * groups * 2;
-}
+// (sd_groupnorm_ws_floats, gn_slab_tokens: host_plan.hpp)
 
 // in_pad / out_pad: the input / output is in the padded layout (tok_row); the output's border rows are zeroed
 // tokens per statistics slab: small slabs = many workgroups (the pass is latency-bound on few), at most 1024 slabs per image
-static int gn_slab_tokens(int HW) { int s = 64; while ((HW + s - 1) / s > 1024) s *= 2; return s; }
+
 
 hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, const float* gamma, const float* beta, uint16_t* y,
                         int n, int H, int W, int C, int groups, float eps, int silu, int in_pad, int out_pad, float* ws,

@@ -337,7 +337,8 @@ hipError_t launch_rows_split(const float* x, int64_t ld_in, uint16_t* out, int64
 hipError_t launch_attention_split(const float* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len, int heads,
                                   int causal, hipStream_t stream, const int32_t* pfx) {
     if (n_seq <= 0) return hipSuccess;
-    if (seq_len < 1 || seq_len > 288 || heads < 1 || (pfx && (!starts || !causal))) return hipErrorInvalidValue;
+    // K / V of a head as hi | lo images: 576 bytes per key row, 160 KB of LDS -> 272 keys (17 tiles: the 257 tokens of ViT-L/14)
+    if (seq_len < 1 || seq_len > 272 || heads < 1 || (pfx && (!starts || !causal))) return hipErrorInvalidValue;
     const int NT = (seq_len + 15) / 16;
     if (causal) {
         if (NT <= 2) return launch_split_one<2, true>(qkv, out, starts, n_seq, seq_len, heads, stream, pfx);

@@ -53,6 +53,7 @@ struct Run {
     bool dry;                 // sizing pass: allocate, launch nothing
     char* base = nullptr;
     size_t off = 0, high = 0;
+    size_t cap = 0;           // bytes behind `base` (the real pass): an allocation beyond it is an error, never a wild pointer
     int rc = TVC_OK;
     // K split of a GEMM, chosen from the PER-SAMPLE shape only (never from the launch size): every sample's arithmetic is
     // then the same whatever batch it is generated in, so an image is bit-for-bit independent of its batch mates and of the
@@ -94,6 +95,10 @@ struct Run {
         void* p = base ? base + off : nullptr;
         off += bytes;
         if (off > high) high = off;
+        if (base && off > cap) {          // the sizing pass and the real pass must walk the same allocations
+            if (rc == TVC_OK) rc = fail(h, TVC_E_STATE, "tvc_sd: arena overrun (the dry run sized " + std::to_string(cap) + " bytes)");
+            return nullptr;
+        }
         return p;
     }
     // GEMM operands get readable rows up to the next multiple of 256 (+ one tile): gemm.hip's ring form stages whole tiles
@@ -481,6 +486,7 @@ int with_arena(tvc_handle* h, hipStream_t st, Slot slot, F&& body) {
     if (rc) return rc;
     Run run{h, h->sd, st, false};
     run.base = (char*)h->ws[slot].p;
+    run.cap = h->ws[slot].n;
     body(run);
     return run.rc;
 }

@@ -23,16 +23,17 @@ struct SBufs { float *X, *QKV, *U, *D1, *D2, *CLS; uint16_t *Hs, *Ms; };
 
 int64_t pad_tile_rows(int64_t rows) { return (rows + 255) / 256 * 256 + 256; }
 
-int ensure_split_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq, int wso, SBufs* b, size_t u_min = 0) {
+int ensure_split_ws(tvc_handle* h, const tvc_tower_arch& a, int64_t rows, int n_seq, int wso, SBufs* b, size_t u_min = 0, size_t m_min = 0) {
     int rc;
     const int64_t rp = pad_tile_rows(rows);             // GEMM operands: readable rows to the next tile (+ one)
-    size_t u_bytes = (size_t)rp * a.mlp * 4;
+    size_t u_bytes = (size_t)rp * a.mlp * 4, m_bytes = (size_t)rp * a.mlp * 2 * 2;
     if (u_bytes < u_min) u_bytes = u_min;
+    if (m_bytes < m_min) m_bytes = m_min;
     if ((rc = ensure(h, (Slot)(WS_SX + wso), (size_t)rp * a.width * 4))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SH + wso), (size_t)rp * a.width * 2 * 2))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SQKV + wso), (size_t)rp * a.width * 3 * 4))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SU + wso), u_bytes))) return rc;
-    if ((rc = ensure(h, (Slot)(WS_SM + wso), (size_t)rp * a.mlp * 2 * 2))) return rc;
+    if ((rc = ensure(h, (Slot)(WS_SM + wso), m_bytes))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SDELTA1 + wso), (size_t)rp * a.width * 4))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SDELTA2 + wso), (size_t)rp * a.width * 4))) return rc;
     if ((rc = ensure(h, (Slot)(WS_SCLS + wso), (size_t)(n_seq + 8) * a.width * 4))) return rc;
@@ -132,6 +133,14 @@ void tvc_split_free(tvc_handle* h) {
 // ViT-L/14); synchronises the device once.  Called by tvc_set_option(TVC_OPT_TOWER_PRECISION, 2).
 int tvc_split_prepare(tvc_handle* h) {
     if (h->split_ready) return TVC_OK;
+    {
+        // the split attention keeps K and V of a head as hi | lo images in LDS: at most 272 tokens per sequence (the bf16
+        // and fp32 modes take 288, which tvc_create already enforces together with head_dim 64)
+        const tvc_model_desc& md = h->desc;
+        const int Tv = h->has_vision ? (md.image_size / md.patch) * (md.image_size / md.patch) + 1 : 0;
+        if (Tv > 272 || (h->has_text && md.ctx > 272))
+            return fail(h, TVC_E_INVALID, "TVC_OPT_TOWER_PRECISION = 2: sequences longer than 272 tokens are not supported by the split attention");
+    }
     tvc_split_free(h);
     hipStream_t st = nullptr;
     int rc;
@@ -157,10 +166,9 @@ int tvc_split_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float
     const int chunk = B < h->max_chunk_images ? B : h->max_chunk_images;
     SBufs b;
     int rc;
-    // the stem parks its fp32 im2col rows in U and their planes in Ms
-    if ((rc = ensure_split_ws(h, a, (int64_t)chunk * T, chunk, 0, &b, (size_t)pad_tile_rows((int64_t)chunk * P) * K * 4))) return rc;
-    if ((size_t)pad_tile_rows((int64_t)chunk * P) * 2 * Kp * 2 > h->ws[WS_SM].n || (size_t)chunk * P * d * 4 > h->ws[WS_SQKV].n)
-        return fail(h, TVC_E_INVALID, "tvc_encode_image: patch geometry too large for the split-mode workspaces");
+    // the stem parks its fp32 im2col rows in U, their planes in Ms and the patch embeddings in QKV ([n * P, d] fits [rows, 3d])
+    if ((rc = ensure_split_ws(h, a, (int64_t)chunk * T, chunk, 0, &b, (size_t)pad_tile_rows((int64_t)chunk * P) * K * 4,
+                              (size_t)pad_tile_rows((int64_t)chunk * P) * 2 * Kp * 2))) return rc;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int n = (B - b0 < chunk) ? B - b0 : chunk;
         const float* pix = pix_dev + (size_t)b0 * 3 * m.image_size * m.image_size;
@@ -265,8 +273,8 @@ extern "C" int tvc_gemm_split(tvc_handle* h, const float* w_dev, const float* x_
 extern "C" int tvc_attention_split(tvc_handle* h, const float* qkv_dev, uint16_t* out_planes_dev, const int32_t* starts_dev,
                                    int32_t n_seq, int32_t seq_len, int32_t heads, int32_t causal, void* stream) {
     if (!h) return TVC_E_INVALID;
-    if (!qkv_dev || !out_planes_dev || seq_len < 1 || seq_len > 288 || heads < 1 || n_seq < 0)
-        return fail(h, TVC_E_INVALID, "tvc_attention_split: need 1 <= seq_len <= 288 and non-NULL buffers");
+    if (!qkv_dev || !out_planes_dev || seq_len < 1 || seq_len > 272 || heads < 1 || n_seq < 0)
+        return fail(h, TVC_E_INVALID, "tvc_attention_split: need 1 <= seq_len <= 272 and non-NULL buffers");
     HIP_TRY(launch_attention_split(qkv_dev, out_planes_dev, starts_dev, n_seq, seq_len, heads, causal, (hipStream_t)stream, nullptr));
     return TVC_OK;
 }

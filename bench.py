@@ -75,6 +75,9 @@ def parse(argv=None):
     p.add_argument("--no-live-traffic", action="store_true",
                    help="do not measure roofline.traffic live (two rocprofv3 --pmc child passes of this command with --steps 1, "
                         "run BEFORE this process touches the GPU; the default N=1 run does, ~1.5 min); fall back to the committed profile")
+    p.add_argument("--sd-model", default="runwayml/stable-diffusion-v1-5",
+                   help="latent-diffusion geometry of the sd_reference extra: the reference's default (src/sd_ref.py:221) or "
+                        "'stabilityai/stable-diffusion-2-1-base' (src/__init__.py:110-113)")
     p.add_argument("--no-parity-modes", action="store_true", help="skip the parity_mode extra (the step in the split-bf16 and fp32 tower modes)")
     p.add_argument("--master-port", type=int, default=0)
     p.add_argument("--dry-run-launch", action="store_true",
@@ -762,7 +765,7 @@ def main():
         # steps (experiments/defenses/generative_ref.py:24) at 64 x 64 latents, guidance 7.5, VAE decode to 512 x 512,
         # device-side preprocessing, ONE image-tower launch -> reference embeddings
         torch.cuda.empty_cache()
-        sd = pkg.StableDiffusionModel(pkg.SDModelConfig(device=str(dev), random_init=True), clip_model=clip)
+        sd = pkg.StableDiffusionModel(pkg.SDModelConfig(model_name=a.sd_model, device=str(dev), random_init=True), clip_model=clip)
         n_img, steps_sd = 12, 20
         prompts = [f"a photo of object number {i}" for i in range(n_img)]
         seeds_sd = list(range(n_img))
@@ -787,7 +790,9 @@ def main():
                                                                 filter_low_quality=False, enable_cache=False), sd_model=sd, clip_model=clip))
         d_full, res_full = timed(lambda: det.batch_detect(images[:4], texts_sd), 2, 1)
         assert len(res_full) == 4 and all("sd_reference" in r["detection_scores"] for r in res_full)
-        out["sd_reference"] = {"images_per_s": round(n_img * 2 / d_sd, 3), "images": n_img, "steps": steps_sd, "latent": "64x64",
+        out["sd_reference"] = {"model": f"{sd.arch.name} geometry ({'v' if sd.arch.prediction_type == 'v_prediction' else 'epsilon'}-prediction, "
+                                        f"heads {[sd.arch.heads_at(i) for i in range(len(sd.arch.block_out_channels))]}, cross-attention {sd.arch.cross_attention_dim}), random init",
+                               "images_per_s": round(n_img * 2 / d_sd, 3), "images": n_img, "steps": steps_sd, "latent": "64x64",
                                "full_defense_qps": round(4 * 2 / d_full, 3),
                                "full_defense_note": "AdversarialDetector.batch_detect with all three methods (text_variants + sd_reference + "
                                                     "consistency), 4 queries x 3 references x 20 steps per batch (BASELINE configs[4])",

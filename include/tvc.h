@@ -49,12 +49,17 @@ enum { TVC_DTYPE_BF16 = 0, TVC_DTYPE_F32 = 1 };
 
 typedef struct tvc_handle tvc_handle;
 
-/* Transformer tower geometry (OpenAI-CLIP style, pre-LN, quick-GELU). */
+/* Transformer tower geometry (CLIP style, pre-LN). */
+enum { TVC_ACT_QUICK_GELU = 0, TVC_ACT_GELU = 1 };
 typedef struct {
     int32_t width;    /* d_model                          */
     int32_t layers;
     int32_t heads;    /* head_dim = width / heads, must be 64 */
     int32_t mlp;      /* hidden size of the MLP           */
+    int32_t act;      /* TVC_ACT_QUICK_GELU: x * sigmoid(1.702 x) (OpenAI CLIP, every tower the detector uses);
+                         TVC_ACT_GELU: the exact erf GELU (OpenCLIP ViT-H/14, the text encoder of Stable Diffusion 2.x) --
+                         applied by a row kernel after a store-only FC1, not in the GEMM epilogue; not available to
+                         tvc_encode_image_grad */
 } tvc_tower_arch;
 
 typedef struct {
@@ -427,7 +432,10 @@ int tvc_layernorm_backward(tvc_handle* h, const float* x_dev, const uint16_t* dy
  * What src/sd_ref.py:389-399 (StableDiffusionModel.generate_image) and experiments/defenses/generative_ref.py:139-147
  * (sd_model.generate) reach through diffusers.StableDiffusionPipeline: the UNet2DConditionModel denoising loop with
  * classifier-free guidance under the PNDM (PLMS) scheduler, then AutoencoderKL.decode.  Geometry = the config.json
- * files the reference holds (cache/sd/models--runwayml--stable-diffusion-v1-5/snapshots/<rev>/{unet,vae,scheduler}).
+ * files the reference holds (cache/sd/models--runwayml--stable-diffusion-v1-5/snapshots/<rev>/{unet,vae,scheduler}), or
+ * Stable Diffusion 2.x (src/__init__.py:110-113 lists stable-diffusion-2-1): per-level head counts, linear proj_in /
+ * proj_out ([C, C] weights -- a 1 x 1 convolution on token rows is the same GEMM), cross-attention width 1024,
+ * optionally v-prediction.
  * Activations are bf16 token-major (NHWC) between GEMMs, statistics / softmax / scheduler arithmetic fp32. */
 typedef struct {
     int32_t in_channels, out_channels;           /* 4, 4                                            */
@@ -436,6 +444,8 @@ typedef struct {
     int32_t down_block_attn[4];                  /* 1, 1, 1, 0 (CrossAttnDownBlock2D x3, DownBlock2D) */
     int32_t layers_per_block;                    /* 2                                               */
     int32_t heads;                               /* 8 ("attention_head_dim": 8 = the head count)    */
+    int32_t heads_per_block[4];                  /* SD 2.x: 5, 10, 20, 20 (head dim 64 at every level); all 0 = `heads` everywhere */
+    int32_t prediction_type;                     /* 0 = epsilon (SD 1.x, 2.1-base), 1 = v_prediction (2.1 at 768 px)  */
     int32_t cross_attention_dim;                 /* 768                                             */
     int32_t norm_groups;                         /* 32                                              */
     float   norm_eps;                            /* 1e-5                                            */

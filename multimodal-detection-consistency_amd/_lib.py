@@ -35,7 +35,7 @@ class TVCError(RuntimeError):
 
 
 class TowerArch(C.Structure):
-    _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32)]
+    _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32), ("act", C.c_int32)]
 
 
 class ModelDesc(C.Structure):
@@ -72,7 +72,8 @@ class SDDesc(C.Structure):
     """``tvc_sd_desc`` (include/tvc.h)."""
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("n_blocks", C.c_int32),
                 ("block_out_channels", C.c_int32 * 4), ("down_block_attn", C.c_int32 * 4),
-                ("layers_per_block", C.c_int32), ("heads", C.c_int32), ("cross_attention_dim", C.c_int32),
+                ("layers_per_block", C.c_int32), ("heads", C.c_int32), ("heads_per_block", C.c_int32 * 4),
+                ("prediction_type", C.c_int32), ("cross_attention_dim", C.c_int32),
                 ("norm_groups", C.c_int32), ("norm_eps", C.c_float),
                 ("vae_n_blocks", C.c_int32), ("vae_block_out_channels", C.c_int32 * 4),
                 ("vae_layers_per_block", C.c_int32), ("latent_channels", C.c_int32), ("vae_scaling", C.c_float),

@@ -16,6 +16,7 @@ class Tower:
     layers: int
     heads: int
     mlp: int
+    act: str = "quick_gelu"     # "quick_gelu" (OpenAI CLIP) or "gelu" (exact erf GELU: OpenCLIP ViT-H/14, the SD-2.x text encoder)
 
 
 @dataclass(frozen=True)
@@ -60,6 +61,13 @@ class ClipArch:
 ARCHS = {
     "ViT-B/32": ClipArch("ViT-B/32", 224, 32, Tower(768, 12, 12, 3072), Tower(512, 12, 8, 2048), 512),
     "ViT-L/14": ClipArch("ViT-L/14", 224, 14, Tower(1024, 24, 16, 4096), Tower(768, 12, 12, 3072), 768),
+    # the text encoder of Stable Diffusion 2.x (text_encoder/config.json of stabilityai/stable-diffusion-2-1-base: OpenCLIP
+    # ViT-H/14's text tower cut to 23 layers -- its penultimate layer --, width 1024, 16 heads, erf GELU, projection 1024).
+    # TEXT ONLY: the vision entry is a placeholder geometry that is never instantiated (ViT-H's 1280-wide vision tower is
+    # outside the kernels' width limit and the detector never uses it).
+    "SD2-text": ClipArch("SD2-text", 224, 14, Tower(1024, 1, 16, 4096, "gelu"), Tower(1024, 23, 16, 4096, "gelu"), 1024),
+    "ViT-T/16-gelu-test": ClipArch("ViT-T/16-gelu-test", 64, 16, Tower(256, 2, 4, 512, "gelu"), Tower(128, 2, 2, 256, "gelu"), 128,
+                                   vocab=49408, ctx=77),
     "ViT-T/16-test": ClipArch("ViT-T/16-test", 64, 16, Tower(256, 2, 4, 512), Tower(128, 2, 2, 256), 128,
                               vocab=49408, ctx=77),
 }

@@ -487,6 +487,43 @@ hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
+// exact GELU 0.5 x (1 + erf(x / sqrt 2)) in place (towers with TVC_ACT_GELU: n % 8 == 0 / n % 4 == 0 -- widths are
+// multiples of 64)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__global__ __launch_bounds__(256) void gelu_erf_bf16_kernel(uint16_t* __restrict__ x, int64_t n8) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (int64_t)gridDim.x * blockDim.x) {
+        u32x4_t v = ((u32x4_t*)x)[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = pack_bf16x2(gelu_erf(__uint_as_float(v[e] << 16)), gelu_erf(__uint_as_float(v[e] & 0xffff0000u)));
+        ((u32x4_t*)x)[t] = v;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_erf_f32_kernel(float* __restrict__ x, int64_t n4) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
+        f32x4_t v = ((f32x4_t*)x)[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        ((f32x4_t*)x)[t] = v;
+    }
+}
+hipError_t launch_gelu_erf_bf16(uint16_t* x, int64_t n, hipStream_t stream) {
+    if (n % 8 != 0 || n < 0) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(gelu_erf_bf16_kernel, dim3((int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384)), dim3(256), 0, stream, x, n8);
+    return hipGetLastError();
+}
+hipError_t launch_gelu_erf_f32(float* x, int64_t n, hipStream_t stream) {
+    if (n % 4 != 0 || n < 0) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(gelu_erf_f32_kernel, dim3((int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384)), dim3(256), 0, stream, x, n4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // split-bf16 planes: out[r, 0:d] = bf16(x), out[r, d:2d] = bf16(x - hi)
 // (planes == 1: hi only).  x ~= hi + lo to ~2^-17 relative.
 // ---------------------------------------------------------------------------

@@ -58,6 +58,7 @@ struct ProfRec {
     int cat;
     double work;
     double big_bytes = 0;     // GEMM launches of >= 64 output tiles (the persistent ring kernels): compulsory HBM bytes
+    int gI = 0, gJ = 0, gK = 0, gP = 0, gS = 0;     // GEMM launches: shape, planes, fixed K split (TVC_PROF_DUMP)
 };
 
 struct tvc_handle {
@@ -175,6 +176,7 @@ inline double gemm_compulsory_bytes(const GemmLaunch& g) {
 inline hipError_t timed_gemm(tvc_handle* h, const GemmLaunch& g, hipStream_t st, int splitk_slot = -1) {
     ProfScope ps(h, st, TVC_PROF_GEMM, gemm_flops(g));
     if (ps.on && (int64_t)((g.I + 255) / 256) * ((g.J + 255) / 256) >= 64) ps.r.big_bytes = gemm_compulsory_bytes(g);
+    if (ps.on) { ps.r.gI = g.I; ps.r.gJ = g.J; ps.r.gK = g.K; ps.r.gP = g.planes; ps.r.gS = g.splitk_fixed; }
     if (splitk_slot >= 0 && h->ws[splitk_slot].p) {
         GemmLaunch g2 = g;
         g2.splitk_ws = (float*)h->ws[splitk_slot].p;

@@ -60,6 +60,9 @@ hipError_t launch_text_embed(const int32_t* tok, const float* tok_emb, const flo
 hipError_t launch_text_lens_scan(const int32_t* tok, int32_t* starts, int32_t* pfx, int n_text, int ctx, int G,
                                  hipStream_t stream, int32_t* lens_ws);
 hipError_t launch_l2norm_rows(float* x, int rows, int d, hipStream_t stream);
+// exact (erf) GELU in place: the activation of towers with TVC_ACT_GELU, after a store-only FC1
+hipError_t launch_gelu_erf_bf16(uint16_t* x, int64_t n, hipStream_t stream);
+hipError_t launch_gelu_erf_f32(float* x, int64_t n, hipStream_t stream);
 hipError_t launch_split_planes(const float* x, uint16_t* out, int64_t rows, int d, int planes,
                                hipStream_t stream);
 hipError_t launch_gather_rows(const uint16_t* bank, int64_t ld, int planes, int D, int64_t R,
@@ -158,7 +161,7 @@ hipError_t launch_gather_f32_rows(const float* x, int64_t ld, const int32_t* idx
 // LayerNorm of x (+ fp32 deltas d1, d2; written back to x when write_x) -> planes [rows, 2d] and / or fp32 rows y32
 hipError_t launch_ln_split(float* x, int64_t x_row_stride, const int32_t* row_idx, const float* d1, const float* d2, int write_x,
                            const float* g, const float* b, uint16_t* planes, float* y32, int rows, int d, hipStream_t stream);
-// fp32 [rows, ld_in] (K columns) -> planes [rows, 2 * Kp] zero padded; gelu != 0: QuickGELU first
+// fp32 [rows, ld_in] (K columns) -> planes [rows, 2 * Kp] zero padded; gelu 1: QuickGELU first, 2: erf GELU first
 hipError_t launch_rows_split(const float* x, int64_t ld_in, uint16_t* out, int64_t rows, int K, int Kp, int gelu, hipStream_t stream);
 // qkv fp32 [rows, 3 * width] -> attention output planes [rows, 2 * width]; ragged / prefix-sharing as launch_attention
 hipError_t launch_attention_split(const float* qkv, uint16_t* out, const int32_t* starts, int n_seq, int seq_len, int heads,

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(256) void ln_split_kernel(float* __restrict__ x, in
     }
 }
 
-// fp32 rows [rows, ld_in] (first K columns used) -> planes [rows, 2 * Kp], zero padded from K to Kp; gelu != 0 applies
-// QuickGELU x * sigmoid(1.702 x) first (exact expf and division, as the fp32 CPU path).  K % 4 == 0, Kp % 4 == 0.
+// fp32 rows [rows, ld_in] (first K columns used) -> planes [rows, 2 * Kp], zero padded from K to Kp; gelu 1 applies
+// QuickGELU x * sigmoid(1.702 x) first (exact expf and division, as the fp32 CPU path), gelu 2 the erf GELU.
+// K % 4 == 0, Kp % 4 == 0.
 __global__ __launch_bounds__(256) void rows_split_kernel(const float* __restrict__ x, int64_t ld_in, uint16_t* __restrict__ out,
                                                          int64_t rows, int K, int Kp, int gelu) {
     const int nv = Kp >> 2;
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256) void rows_split_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float u = v[e];
-            if (gelu) u = u / (1.0f + expf(-1.702f * u));
+            if (gelu == 1) u = u / (1.0f + expf(-1.702f * u));
+            else if (gelu == 2) u = 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
             split2(u, h[e], l[e]);
         }
         uint16_t* o = out + r * (int64_t)(2 * Kp) + c * 4;

@@ -4,6 +4,8 @@
 // except where tvc.h says so.
 #include "handle.hpp"
 
+#include <cstdlib>
+
 // tvc_precise.cpp
 int tvc_precise_encode_image(tvc_handle* h, const float* pix_dev, int32_t B, float* out_dev, int32_t normalize, hipStream_t st);
 int tvc_precise_encode_text(tvc_handle* h, const int32_t* tok_dev, int32_t Tn, float* out_dev, int32_t normalize,
@@ -18,7 +20,7 @@ namespace {
 
 bool tower_ok(const tvc_tower_arch& a) {
     return a.width > 0 && a.layers > 0 && a.heads > 0 && a.width == a.heads * 64 && a.width % 64 == 0 &&
-           a.width <= 1024 && a.mlp > 0 && a.mlp % 64 == 0;
+           a.width <= 1024 && a.mlp > 0 && a.mlp % 64 == 0 && (a.act == TVC_ACT_QUICK_GELU || a.act == TVC_ACT_GELU);
 }
 
 // One transformer tower over `rows` packed token rows (n_seq sequences of seq_len).
@@ -104,8 +106,10 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
                                      st, nullptr, 1));
             g = GemmLaunch();
             g.A = w.w1; g.lda = d; g.I = a.mlp; g.B = pb.H2c; g.ldb = d; g.J = n_seq; g.K = d;
-            g.bias = w.b1; g.out = pb.MLPc; g.ldo = a.mlp; g.epilogue = TVC_EPI_GELU_BF16; g.b_rows_padded = true;
+            g.bias = w.b1; g.out = pb.MLPc; g.ldo = a.mlp; g.b_rows_padded = true;
+            g.epilogue = a.act == TVC_ACT_GELU ? TVC_EPI_BF16 : TVC_EPI_GELU_BF16;
             HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            if (a.act == TVC_ACT_GELU) HIP_TRY(launch_gelu_erf_bf16(pb.MLPc, (int64_t)n_seq * a.mlp, st));
             g = GemmLaunch();
             g.A = w.w2; g.lda = a.mlp; g.I = d; g.B = pb.MLPc; g.ldb = a.mlp; g.J = n_seq; g.K = a.mlp;
             g.bias = w.b2; g.out = pb.D2c; g.ldo = d; g.epilogue = TVC_EPI_BF16; g.b_rows_padded = true;
@@ -137,6 +141,12 @@ int run_layers(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weights* 
             g.out = U; g.epilogue = TVC_EPI_BF16;
             HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
             HIP_TRY(launch_gelu_fwd(U, MLP, (int64_t)rows * a.mlp, st));
+        } else if (a.act == TVC_ACT_GELU) {
+            // erf GELU (the SD-2.x text encoder): store-only FC1, the activation as a streaming pass in place
+            g.out = MLP; g.epilogue = TVC_EPI_BF16;
+            HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
+            ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * a.mlp * 4.0);
+            HIP_TRY(launch_gelu_erf_bf16(MLP, (int64_t)rows * a.mlp, st));
         } else {
             g.out = MLP; g.epilogue = TVC_EPI_GELU_BF16;
             HIP_TRY(timed_gemm(h, g, st, WS_SPLITK + wso));
@@ -632,6 +642,7 @@ int tvc_encode_image_grad(tvc_handle* h, const float* pix_dev, int32_t B, float*
     if (!h->has_vision) return fail(h, TVC_E_STATE, "tvc_encode_image_grad: handle has no vision tower");
     if (B < 1 || !pix_dev || !out_dev) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: bad arguments");
     if (B > h->max_chunk_images) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: B exceeds TVC_OPT_MAX_CHUNK_IMAGES (one pass only)");
+    if (h->desc.vision.act != TVC_ACT_QUICK_GELU) return fail(h, TVC_E_INVALID, "tvc_encode_image_grad: only QuickGELU towers have a backward pass");
     hipStream_t st = (hipStream_t)stream;
     const tvc_model_desc& m = h->desc;
     const tvc_tower_arch& a = m.vision;
@@ -840,15 +851,20 @@ int tvc_profile_end(tvc_handle* h, double* ms, double* work, int64_t* launches, 
     HIP_TRY(hipDeviceSynchronize());
     for (int c = 0; c < TVC_PROF_NCAT; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
     if (big_gemm) big_gemm[0] = big_gemm[1] = big_gemm[2] = 0;
+    // diagnostics (scripts/gemm_shape_table.py): TVC_PROF_DUMP=<file> appends one line per GEMM launch -- I J K planes split ms
+    FILE* dump = nullptr;
+    if (const char* path = getenv("TVC_PROF_DUMP")) dump = fopen(path, "a");
     for (auto& r : h->prof_recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cat >= 0 && r.cat < TVC_PROF_NCAT) {
             ms[r.cat] += t; work[r.cat] += r.work; launches[r.cat] += 1;
             if (big_gemm && r.big_bytes > 0) { big_gemm[0] += r.big_bytes; big_gemm[1] += 1; big_gemm[2] += t; }
+            if (dump && r.cat == TVC_PROF_GEMM) fprintf(dump, "%d %d %d %d %d %.6f\n", r.gI, r.gJ, r.gK, r.gP, r.gS, t);
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     h->prof_recs.clear();
+    if (dump) fclose(dump);
     return TVC_OK;
 }
 

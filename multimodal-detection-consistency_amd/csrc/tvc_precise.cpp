@@ -47,7 +47,8 @@ int run_layers_f32(tvc_handle* h, const tvc_tower_arch& a, const tvc_layer_weigh
         }
         if ((rc = gemm32(h, w.wo, d, d, b.H, rows, w.bo, b.X, d, 2, st))) return rc;          // X += out-proj
         HIP_TRY(launch_layernorm(b.X, d, nullptr, nullptr, 0, w.ln2_g, w.ln2_b, nullptr, (int)rows, d, st, nullptr, 0, nullptr, b.H));
-        if ((rc = gemm32(h, w.w1, a.mlp, d, b.H, rows, w.b1, b.MLP, a.mlp, 1, st))) return rc; // QuickGELU
+        if ((rc = gemm32(h, w.w1, a.mlp, d, b.H, rows, w.b1, b.MLP, a.mlp, a.act == TVC_ACT_GELU ? 0 : 1, st))) return rc; // QuickGELU in the epilogue
+        if (a.act == TVC_ACT_GELU) HIP_TRY(launch_gelu_erf_f32(b.MLP, rows * a.mlp, st));                                   // erf GELU: a row pass
         if ((rc = gemm32(h, w.w2, d, a.mlp, b.MLP, rows, w.b2, b.X, d, 2, st))) return rc;     // X += fc2
     }
     return TVC_OK;

@@ -284,8 +284,8 @@ struct Run {
     }
 
     // Transformer2DModel with one BasicTransformerBlock; ctx16 bf16 [n * ctx, cross_attention_dim]
-    Act transformer(const Act& x, const std::string& p, const uint16_t* ctx16) {
-        const int C = x.C, heads = S->d.heads, dh = C / heads, T = x.H * x.W, n = x.n;
+    Act transformer(const Act& x, const std::string& p, const uint16_t* ctx16, int heads) {
+        const int C = x.C, dh = C / heads, T = x.H * x.W, n = x.n;
         const std::string t = p + "transformer_blocks.0.";
         Act out = act(n, x.H, x.W, C);
         const size_t mark = off;
@@ -402,12 +402,13 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
     std::vector<Act> skips;
     skips.push_back(x);
     const float eps = d.norm_eps;
+    auto heads_at = [&](int level) { return d.heads_per_block[level] > 0 ? d.heads_per_block[level] : d.heads; };
     for (int i = 0; i < nb; ++i) {
         const int c = d.block_out_channels[i];
         for (int j = 0; j < d.layers_per_block; ++j) {
             const std::string pi = "down_blocks." + std::to_string(i);
             x = R.resnet(x, pi + ".resnets." + std::to_string(j) + ".", c, tadd, eps);
-            if (d.down_block_attn[i]) x = R.transformer(x, pi + ".attentions." + std::to_string(j) + ".", ctx16);
+            if (d.down_block_attn[i]) x = R.transformer(x, pi + ".attentions." + std::to_string(j) + ".", ctx16, heads_at(i));
             skips.push_back(x);
         }
         if (i != nb - 1) {
@@ -417,7 +418,7 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
     }
     const int cm = d.block_out_channels[nb - 1];
     x = R.resnet(x, "mid_block.resnets.0.", cm, tadd, eps);
-    x = R.transformer(x, "mid_block.attentions.0.", ctx16);
+    x = R.transformer(x, "mid_block.attentions.0.", ctx16, heads_at(nb - 1));
     x = R.resnet(x, "mid_block.resnets.1.", cm, tadd, eps);
     for (int i = 0; i < nb; ++i) {
         const int c = d.block_out_channels[nb - 1 - i];
@@ -429,7 +430,7 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
             Act cat = R.act(x.n, x.H, x.W, x.C + sk.C);
             if (R.live()) R.hip(sd_concat(x.p, x.C, sk.p, sk.C, cat.p, cat.tok(), R.st), "sd_concat");
             x = R.resnet(cat, pi + ".resnets." + std::to_string(j) + ".", c, tadd, eps);
-            if (attn) x = R.transformer(x, pi + ".attentions." + std::to_string(j) + ".", ctx16);
+            if (attn) x = R.transformer(x, pi + ".attentions." + std::to_string(j) + ".", ctx16, heads_at(nb - 1 - i));
         }
         if (i != nb - 1) x = R.upsample_conv(x, pi + ".upsamplers.0.conv.", c);
     }
@@ -502,6 +503,15 @@ int check_latent_hw(tvc_handle* h, int H, int W, bool unet, bool vae, const char
     return TVC_OK;
 }
 
+// heads of the Transformer2DModel whose state-dict prefix is `p` ("down_blocks.<i>.", "up_blocks.<i>.", "mid_block.")
+int block_heads(const tvc_sd_desc& d, const std::string& p) {
+    int level = d.n_blocks - 1;
+    if (p.compare(0, 12, "down_blocks.") == 0 && p.size() > 12) level = p[12] - '0';
+    else if (p.compare(0, 10, "up_blocks.") == 0 && p.size() > 10) level = d.n_blocks - 1 - (p[10] - '0');
+    if (level < 0 || level >= d.n_blocks) level = d.n_blocks - 1;
+    return d.heads_per_block[level] > 0 ? d.heads_per_block[level] : d.heads;
+}
+
 int need_sd(tvc_handle* h, bool unet, bool vae, const char* who) {
     if (!h) return TVC_E_INVALID;
     if (!h->sd || (unet && !h->sd->has_unet) || (vae && !h->sd->has_vae))
@@ -518,12 +528,13 @@ int tvc_sd_load(tvc_handle* h, const tvc_sd_desc* desc, const tvc_named_tensor* 
     if (!desc || !tensors || n_tensors <= 0) return fail(h, TVC_E_INVALID, "tvc_sd_load: NULL desc / tensors");
     const tvc_sd_desc& d = *desc;
     if (d.n_blocks < 1 || d.n_blocks > 4 || d.vae_n_blocks < 1 || d.vae_n_blocks > 4 || d.norm_groups < 1 || d.norm_groups > 32 ||
-        d.heads < 1 || d.in_channels * 9 > 64 || d.latent_channels * 9 > 64 || d.latent_channels > 8 || d.ctx < 1 ||
+        d.heads < 1 || d.prediction_type < 0 || d.prediction_type > 1 || d.in_channels * 9 > 64 || d.latent_channels * 9 > 64 || d.latent_channels > 8 || d.ctx < 1 ||
         d.cross_attention_dim % 64 != 0 || d.layers_per_block < 1 || d.vae_layers_per_block < 1 || d.out_channels < 1)
         return fail(h, TVC_E_INVALID, "tvc_sd_load: unsupported geometry");
     for (int i = 0; i < d.n_blocks; ++i) {
         const int c = d.block_out_channels[i];
-        const int dh = c % d.heads == 0 ? c / d.heads : 0;
+        const int nh = d.heads_per_block[i] > 0 ? d.heads_per_block[i] : d.heads;
+        const int dh = c % nh == 0 ? c / nh : 0;
         const bool dh_ok = dh == 8 || dh == 16 || dh == 24 || dh == 32 || dh == 40 || dh == 48 || dh == 56 || dh == 64 || dh == 80 ||
                            dh == 96 || dh == 128 || dh == 160;         // the instantiations of sd_flash_attention_kernel
         if (c % 64 != 0 || c % d.norm_groups != 0 || (c / d.norm_groups) % 2 != 0 || !dh_ok || c > 1536)
@@ -701,9 +712,16 @@ static int sd_generate_chunk(tvc_handle* h, const float* cond_dev, const float* 
         }
         const float a_t = acp(tt), a_prev = acp(prev_t);
         const float b_t = 1.f - a_t, b_prev = 1.f - a_prev;
-        const float cs = sqrtf(a_prev / a_t);
+        float cs = sqrtf(a_prev / a_t);
         const float denom = a_t * sqrtf(b_prev) + sqrtf(a_t * b_t * a_prev);
-        HIP_TRY(sd_lincomb(latents_dev, sample, cs, (a_prev - a_t) / denom, e0, c0, e1, c1, e2, c2, e3, c3, ne, st));
+        float ce = (a_prev - a_t) / denom;
+        if (d.prediction_type == 1) {
+            // v-prediction (PNDMScheduler._get_prev_sample): the combined model output E stands for
+            // sqrt(a_t) E + sqrt(b_t) sample -- folded into the two coefficients of prev = cs * sample - ce * E
+            cs -= ce * sqrtf(b_t);
+            ce *= sqrtf(a_t);
+        }
+        HIP_TRY(sd_lincomb(latents_dev, sample, cs, ce, e0, c0, e1, c1, e2, c2, e3, c3, ne, st));
         ++counter;
     }
     return TVC_OK;
@@ -771,7 +789,7 @@ int tvc_sd_block(tvc_handle* h, int32_t kind, const char* prefix, const float* x
         } else if (kind == 1) {
             uint16_t* ctx16 = (uint16_t*)R.alloc((size_t)pad_rows((int64_t)n * d.ctx) * d.cross_attention_dim * 2);
             if (R.live()) R.hip(sd_cast_silu(ctx_dev, ctx16, (int64_t)n * d.ctx * d.cross_attention_dim, 0, R.st), "ctx cast");
-            y = R.transformer(x, p, ctx16);
+            y = R.transformer(x, p, ctx16, block_heads(d, p));
         } else if (kind == 2) {
             y = R.vae_attention(x, p);
         } else if (kind == 3) {

@@ -87,7 +87,7 @@ int run_layers_split(tvc_handle* h, const tvc_tower_arch& a, const SplitLayer* s
         if ((rc = gemm3(h, sw[l].w1, a.mlp, d, b.Hs, rows, w.b1, b.U, a.mlp, st, splitk_slot))) return rc;
         {
             ProfScope ps(h, st, TVC_PROF_ROWOPS, (double)rows * a.mlp * 8.0);
-            HIP_TRY(launch_rows_split(b.U, a.mlp, b.Ms, rows, a.mlp, a.mlp, 1, st));
+            HIP_TRY(launch_rows_split(b.U, a.mlp, b.Ms, rows, a.mlp, a.mlp, a.act == TVC_ACT_GELU ? 2 : 1, st));
         }
         if ((rc = gemm3(h, sw[l].w2, d, a.mlp, b.Ms, rows, w.b2, b.D2, d, st, splitk_slot))) return rc;
         pending = true;

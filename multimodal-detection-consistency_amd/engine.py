@@ -78,8 +78,10 @@ class TVCEngine:
             desc = vis = txt = None
             if arch is not None:
                 desc = _lib.ModelDesc(arch.image_size, arch.patch, arch.vocab, arch.ctx, arch.embed_dim,
-                                      _lib.TowerArch(arch.vision.width, arch.vision.layers, arch.vision.heads, arch.vision.mlp),
-                                      _lib.TowerArch(arch.text.width, arch.text.layers, arch.text.heads, arch.text.mlp))
+                                      _lib.TowerArch(arch.vision.width, arch.vision.layers, arch.vision.heads, arch.vision.mlp,
+                                                     int(arch.vision.act == "gelu")),
+                                      _lib.TowerArch(arch.text.width, arch.text.layers, arch.text.heads, arch.text.mlp,
+                                                     int(arch.text.act == "gelu")))
                 if vision_w is not None:
                     vis = self._vision_struct(arch, vision_w)
                 if text_w is not None:

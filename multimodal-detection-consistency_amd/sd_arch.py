@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -29,6 +29,13 @@ class SDArch:
     down_block_attn: Tuple[bool, ...] = (True, True, True, False)     # CrossAttnDownBlock2D x3, DownBlock2D
     layers_per_block: int = 2
     heads: int = 8                       # "attention_head_dim": 8 (the number of heads in this diffusers version)
+    # SD 2.x: "attention_head_dim": [5, 10, 20, 20] -- the NUMBER of heads per resolution level (head dim 64 everywhere);
+    # None = `heads` at every level (SD 1.x)
+    heads_per_block: Optional[Tuple[int, ...]] = None
+    linear_projection: bool = False      # "use_linear_projection": Transformer2DModel.proj_in / proj_out are nn.Linear [C, C]
+    prediction_type: str = "epsilon"     # scheduler_config.json: "epsilon" (SD 1.x, 2.1-base) or "v_prediction" (2.1 at 768 px)
+    text_arch: str = "ViT-L/14"          # text_encoder/config.json: CLIP ViT-L/14 (768) or "SD2-text" (OpenCLIP ViT-H/14, 1024)
+    name: str = "runwayml/stable-diffusion-v1-5"
     cross_attention_dim: int = 768
     norm_groups: int = 32
     norm_eps: float = 1e-5
@@ -49,8 +56,26 @@ class SDArch:
     def time_dim(self) -> int:
         return self.block_out_channels[0] * 4
 
-    def head_dim(self, channels: int) -> int:
-        return channels // self.heads
+    def heads_at(self, level: int) -> int:
+        return self.heads_per_block[level] if self.heads_per_block is not None else self.heads
+
+    def head_dim(self, channels: int, level: int = 0) -> int:
+        return channels // self.heads_at(level)
+
+    @staticmethod
+    def sd15() -> "SDArch":
+        """runwayml/stable-diffusion-v1-5: the geometry of the config.json files the reference holds (its default,
+        src/sd_ref.py:221)."""
+        return SDArch()
+
+    @staticmethod
+    def sd21_base() -> "SDArch":
+        """stabilityai/stable-diffusion-2-1-base (listed as supported by the reference, src/__init__.py:110-113; the model
+        BASELINE configs[4] names): per-level head counts 5 / 10 / 20 / 20 at head dim 64, linear proj_in / proj_out,
+        cross-attention onto the 1024-wide OpenCLIP ViT-H/14 text states, epsilon prediction at 512 px.  (The 768-px
+        "stable-diffusion-2-1" differs by prediction_type="v_prediction" and sample_size 96.)"""
+        return SDArch(heads_per_block=(5, 10, 20, 20), linear_projection=True, cross_attention_dim=1024,
+                      text_arch="SD2-text", name="stabilityai/stable-diffusion-2-1-base")
 
 
 def _resnet_shapes(p: str, cin: int, cout: int, temb: int) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -65,10 +90,11 @@ def _resnet_shapes(p: str, cin: int, cout: int, temb: int) -> List[Tuple[str, Tu
     return s
 
 
-def _transformer_shapes(p: str, c: int, ctx: int) -> List[Tuple[str, Tuple[int, ...]]]:
+def _transformer_shapes(p: str, c: int, ctx: int, linear: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
     t = p + "transformer_blocks.0."
+    pj = (c, c) if linear else (c, c, 1, 1)           # use_linear_projection: nn.Linear instead of a 1 x 1 convolution
     s = [(p + "norm.weight", (c,)), (p + "norm.bias", (c,)),
-         (p + "proj_in.weight", (c, c, 1, 1)), (p + "proj_in.bias", (c,))]
+         (p + "proj_in.weight", pj), (p + "proj_in.bias", (c,))]
     for i in (1, 2, 3):
         s += [(t + f"norm{i}.weight", (c,)), (t + f"norm{i}.bias", (c,))]
     for a, kv in (("attn1", c), ("attn2", ctx)):
@@ -76,7 +102,7 @@ def _transformer_shapes(p: str, c: int, ctx: int) -> List[Tuple[str, Tuple[int, 
               (t + f"{a}.to_out.0.weight", (c, c)), (t + f"{a}.to_out.0.bias", (c,))]
     s += [(t + "ff.net.0.proj.weight", (8 * c, c)), (t + "ff.net.0.proj.bias", (8 * c,)),
           (t + "ff.net.2.weight", (c, 4 * c)), (t + "ff.net.2.bias", (c,)),
-          (p + "proj_out.weight", (c, c, 1, 1)), (p + "proj_out.bias", (c,))]
+          (p + "proj_out.weight", pj), (p + "proj_out.bias", (c,))]
     return s
 
 
@@ -92,11 +118,11 @@ def unet_param_shapes(a: SDArch) -> List[Tuple[str, Tuple[int, ...]]]:
         for j in range(a.layers_per_block):
             s += _resnet_shapes(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else c, c, T)
             if a.down_block_attn[i]:
-                s += _transformer_shapes(f"down_blocks.{i}.attentions.{j}.", c, a.cross_attention_dim)
+                s += _transformer_shapes(f"down_blocks.{i}.attentions.{j}.", c, a.cross_attention_dim, a.linear_projection)
         if i != len(ch) - 1:
             s += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (c, c, 3, 3)), (f"down_blocks.{i}.downsamplers.0.conv.bias", (c,))]
     m = ch[-1]
-    s += _resnet_shapes("mid_block.resnets.0.", m, m, T) + _transformer_shapes("mid_block.attentions.0.", m, a.cross_attention_dim) + \
+    s += _resnet_shapes("mid_block.resnets.0.", m, m, T) + _transformer_shapes("mid_block.attentions.0.", m, a.cross_attention_dim, a.linear_projection) + \
         _resnet_shapes("mid_block.resnets.1.", m, m, T)
     rev = list(reversed(ch))
     attn_rev = list(reversed(a.down_block_attn))
@@ -108,7 +134,7 @@ def unet_param_shapes(a: SDArch) -> List[Tuple[str, Tuple[int, ...]]]:
             res_in = prev if j == 0 else c
             s += _resnet_shapes(f"up_blocks.{i}.resnets.{j}.", res_in + res_skip, c, T)
             if attn_rev[i]:
-                s += _transformer_shapes(f"up_blocks.{i}.attentions.{j}.", c, a.cross_attention_dim)
+                s += _transformer_shapes(f"up_blocks.{i}.attentions.{j}.", c, a.cross_attention_dim, a.linear_projection)
         if i != len(ch) - 1:
             s += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (c, c, 3, 3)), (f"up_blocks.{i}.upsamplers.0.conv.bias", (c,))]
         prev = c

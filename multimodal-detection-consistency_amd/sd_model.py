@@ -101,6 +101,11 @@ def sd_desc(a: SDArch) -> "_lib.SDDesc":
         d.block_out_channels[i] = c
         d.down_block_attn[i] = int(a.down_block_attn[i])
     d.layers_per_block, d.heads, d.cross_attention_dim = a.layers_per_block, a.heads, a.cross_attention_dim
+    for i in range(len(a.block_out_channels)):
+        d.heads_per_block[i] = a.heads_per_block[i] if a.heads_per_block is not None else 0
+    if a.prediction_type not in ("epsilon", "v_prediction"):
+        raise ValueError(f"unsupported prediction_type {a.prediction_type!r}")
+    d.prediction_type = int(a.prediction_type == "v_prediction")
     d.norm_groups, d.norm_eps = a.norm_groups, a.norm_eps
     d.vae_n_blocks = len(a.vae_block_out_channels)
     for i, c in enumerate(a.vae_block_out_channels):
@@ -200,20 +205,24 @@ class SDModelConfig:
     random_init: bool = False                               # explicit opt-in: seeded random UNet / VAE (/ text tower) weights
     unet_weights: Optional[str] = None                      # diffusers unet / vae safetensors files, if present
     vae_weights: Optional[str] = None
-    text_model: str = "ViT-L/14"                            # text_encoder/config.json: CLIP ViT-L/14 text tower
+    text_model: Optional[str] = None                        # conditioning tower; None = the architecture's (SDArch.text_arch:
+                                                            # CLIP ViT-L/14 for SD 1.x, "SD2-text" = OpenCLIP ViT-H/14 for SD 2.x)
     tokenizer_dir: Optional[str] = None
 
 
 class StableDiffusionModel:
     """``generate_image`` / ``generate`` as the reference calls them, plus the batched ``generate_batch``."""
 
-    PAD_ID = synth.EOT          # the SD tokenizer pads with <|endoftext|> (tokenizer/special_tokens_map.json)
+    PAD_ID = synth.EOT          # the SD 1.x tokenizer pads with <|endoftext|> (tokenizer/special_tokens_map.json); SD 2.x pads with "!" (id 0)
 
     def __init__(self, config: Optional[SDModelConfig] = None, clip_model=None, arch: Optional[SDArch] = None,
                  weights: Optional[tuple] = None):
         from .clip import BPETokenizer, HashTokenizer
         self.config = config or SDModelConfig()
-        self.arch = arch or SDArch()
+        if arch is None:
+            # src/__init__.py:110-113: "stable-diffusion-v1-5" (the reference's default, src/sd_ref.py:221) and "stable-diffusion-2-1"
+            arch = SDArch.sd21_base() if "stable-diffusion-2" in self.config.model_name else SDArch.sd15()
+        self.arch = arch
         dev = self.config.device
         self.device = torch.device("cuda:0" if dev in ("cuda", "auto") else dev)
         # conditioning tower: the caller's CLIP when its text tower has the UNet's cross-attention width
@@ -227,7 +236,7 @@ class StableDiffusionModel:
         if clip_model is not None and clip_model.arch.text.width == self.arch.cross_attention_dim:
             self.text_engine, self.text_arch, self.tokenizer = clip_model.engine, clip_model.arch, clip_model.tokenizer
         else:
-            self.text_arch = get_arch(self.config.text_model)
+            self.text_arch = get_arch(self.config.text_model if self.config.text_model else self.arch.text_arch)
             if self.text_arch.text.width != self.arch.cross_attention_dim:
                 raise ValueError("the text tower's width must equal the UNet's cross_attention_dim")
             if not self.config.random_init:
@@ -255,7 +264,8 @@ class StableDiffusionModel:
         ids = self.tokenizer(list(prompts)).clone()
         eot = ids.argmax(dim=1)
         pos = torch.arange(ids.shape[1]).unsqueeze(0)
-        ids[pos > eot.unsqueeze(1)] = self.PAD_ID               # CLIP pads with 0, the SD pipeline with the EOT id
+        pad = 0 if self.arch.text_arch == "SD2-text" else self.PAD_ID
+        ids[pos > eot.unsqueeze(1)] = pad                       # CLIP pads with 0, the SD 1.x pipeline with the EOT id
         return ids
 
     def encode_prompts(self, prompts: Sequence[str]) -> torch.Tensor:

@@ -41,8 +41,9 @@ def _quick_gelu(x: torch.Tensor) -> torch.Tensor:
     return x * torch.sigmoid(1.702 * x)
 
 
-def _block(x: torch.Tensor, lw: Dict[str, torch.Tensor], heads: int, causal: bool) -> torch.Tensor:
-    """One pre-LN residual attention block.  x: [B, T, d]."""
+def _block(x: torch.Tensor, lw: Dict[str, torch.Tensor], heads: int, causal: bool, act: str = "quick_gelu") -> torch.Tensor:
+    """One pre-LN residual attention block.  x: [B, T, d].  act: "quick_gelu" (OpenAI CLIP) or "gelu" (nn.GELU(), the
+    exact erf form: OpenCLIP ViT-H/14, the text encoder of Stable Diffusion 2.x)."""
     B, T, d = x.shape
     dh = d // heads
     h = F.layer_norm(x, (d,), lw['ln1_g'], lw['ln1_b'], LN_EPS)
@@ -59,13 +60,14 @@ def _block(x: torch.Tensor, lw: Dict[str, torch.Tensor], heads: int, causal: boo
     o = (p @ v).transpose(1, 2).reshape(B, T, d)
     x = x + o @ lw['wo'].t() + lw['bo']
     h = F.layer_norm(x, (d,), lw['ln2_g'], lw['ln2_b'], LN_EPS)
-    h = _quick_gelu(h @ lw['w1'].t() + lw['b1'])
+    u = h @ lw['w1'].t() + lw['b1']
+    h = F.gelu(u) if act == "gelu" else _quick_gelu(u)
     x = x + h @ lw['w2'].t() + lw['b2']
     return x
 
 
 def vision_forward(w: Dict, pixels: torch.Tensor, heads: int, patch: int,
-                   normalize: bool = True) -> torch.Tensor:
+                   normalize: bool = True, act: str = "quick_gelu") -> torch.Tensor:
     """pixels [B, 3, H, W] fp32 -> [B, D] (L2-normalised when ``normalize``)."""
     B, C, H, W = pixels.shape
     gh, gw = H // patch, W // patch
@@ -77,7 +79,7 @@ def vision_forward(w: Dict, pixels: torch.Tensor, heads: int, patch: int,
     x = torch.cat([w['cls'].expand(B, 1, d), x], dim=1) + w['pos']
     x = F.layer_norm(x, (d,), w['ln_pre_g'], w['ln_pre_b'], LN_EPS)
     for lw in w['layers']:
-        x = _block(x, lw, heads, causal=False)
+        x = _block(x, lw, heads, causal=False, act=act)
     x = F.layer_norm(x[:, 0], (d,), w['ln_post_g'], w['ln_post_b'], LN_EPS)
     x = x @ w['proj'].t()
     if normalize:
@@ -86,13 +88,13 @@ def vision_forward(w: Dict, pixels: torch.Tensor, heads: int, patch: int,
 
 
 def text_forward(w: Dict, tokens: torch.Tensor, heads: int,
-                 normalize: bool = True) -> torch.Tensor:
+                 normalize: bool = True, act: str = "quick_gelu") -> torch.Tensor:
     """tokens [B, ctx] int -> [B, D].  Pooled at ``tokens.argmax(-1)`` (EOT)."""
     B, T = tokens.shape
     d = w['tok_emb'].shape[1]
     x = w['tok_emb'][tokens.long()] + w['pos'][:T]
     for lw in w['layers']:
-        x = _block(x, lw, heads, causal=True)
+        x = _block(x, lw, heads, causal=True, act=act)
     x = F.layer_norm(x, (d,), w['ln_final_g'], w['ln_final_b'], LN_EPS)
     x = x[torch.arange(B), tokens.long().argmax(dim=-1)]
     x = x @ w['proj'].t()
@@ -101,7 +103,7 @@ def text_forward(w: Dict, tokens: torch.Tensor, heads: int,
     return x
 
 
-def text_hidden(w: Dict, tokens: torch.Tensor, heads: int) -> torch.Tensor:
+def text_hidden(w: Dict, tokens: torch.Tensor, heads: int, act: str = "quick_gelu") -> torch.Tensor:
     """tokens [B, ctx] int -> [B, ctx, d]: ln_final of the hidden state at every position =
     ``transformers.CLIPTextModel(...).last_hidden_state`` (the conditioning of the SD UNet; the reference reaches
     it through the absent ``StableDiffusionModel.generate_image``, /root/reference/src/sd_ref.py:389-412)."""
@@ -109,7 +111,7 @@ def text_hidden(w: Dict, tokens: torch.Tensor, heads: int) -> torch.Tensor:
     d = w['tok_emb'].shape[1]
     x = w['tok_emb'][tokens.long()] + w['pos'][:T]
     for lw in w['layers']:
-        x = _block(x, lw, heads, causal=True)
+        x = _block(x, lw, heads, causal=True, act=act)
     return F.layer_norm(x, (d,), w['ln_final_g'], w['ln_final_b'], LN_EPS)
 
 

@@ -62,12 +62,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> 
 
 
 def transformer(w: Dict, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int, groups: int) -> torch.Tensor:
-    """``Transformer2DModel`` with one ``BasicTransformerBlock`` (conv 1x1 in / out projections)."""
+    """``Transformer2DModel`` with one ``BasicTransformerBlock``; ``proj_in`` / ``proj_out`` are 1 x 1 convolutions
+    (SD 1.x) or, with ``use_linear_projection`` (SD 2.x: 2-D weights), ``nn.Linear`` applied after / before the reshape."""
     B, C, H, W = x.shape
     t = p + "transformer_blocks.0."
+    linear = w[p + "proj_in.weight"].dim() == 2
     h = F.group_norm(x, groups, w[p + "norm.weight"], w[p + "norm.bias"], 1e-6)
-    h = F.conv2d(h, w[p + "proj_in.weight"], w[p + "proj_in.bias"])
-    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    if linear:
+        h = F.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, C), w[p + "proj_in.weight"], w[p + "proj_in.bias"])
+    else:
+        h = F.conv2d(h, w[p + "proj_in.weight"], w[p + "proj_in.bias"])
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     n = F.layer_norm(h, (C,), w[t + "norm1.weight"], w[t + "norm1.bias"], 1e-5)
     a = attention(F.linear(n, w[t + "attn1.to_q.weight"]), F.linear(n, w[t + "attn1.to_k.weight"]),
                   F.linear(n, w[t + "attn1.to_v.weight"]), heads)
@@ -80,6 +85,9 @@ def transformer(w: Dict, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int,
     g = F.linear(n, w[t + "ff.net.0.proj.weight"], w[t + "ff.net.0.proj.bias"])
     val, gate = g.chunk(2, dim=-1)
     h = h + F.linear(val * F.gelu(gate), w[t + "ff.net.2.weight"], w[t + "ff.net.2.bias"])
+    if linear:
+        h = F.linear(h, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
+        return x + h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
     return x + F.conv2d(h, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
 
@@ -88,7 +96,8 @@ def transformer(w: Dict, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int,
 def unet_forward(w: Dict, arch, sample: torch.Tensor, t, ctx: torch.Tensor) -> torch.Tensor:
     """sample [B, 4, H, W], t scalar or [B], ctx [B, 77, 768] -> predicted noise [B, 4, H, W]."""
     B = sample.shape[0]
-    ch, G, eps, heads = arch.block_out_channels, arch.norm_groups, arch.norm_eps, arch.heads
+    ch, G, eps = arch.block_out_channels, arch.norm_groups, arch.norm_eps
+    heads_at = lambda lvl: arch.heads_per_block[lvl] if getattr(arch, "heads_per_block", None) is not None else arch.heads
     tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1).expand(B) if not torch.is_tensor(t) or t.dim() == 0 else t
     temb = timestep_embedding(tt, ch[0])
     temb = F.linear(F.silu(F.linear(temb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"])),
@@ -99,14 +108,14 @@ def unet_forward(w: Dict, arch, sample: torch.Tensor, t, ctx: torch.Tensor) -> t
         for j in range(arch.layers_per_block):
             x = resnet(w, f"down_blocks.{i}.resnets.{j}.", x, temb, G, eps)
             if arch.down_block_attn[i]:
-                x = transformer(w, f"down_blocks.{i}.attentions.{j}.", x, ctx, heads, G)
+                x = transformer(w, f"down_blocks.{i}.attentions.{j}.", x, ctx, heads_at(i), G)
             skips.append(x)
         if i != len(ch) - 1:
             x = F.conv2d(x, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
                          stride=2, padding=1)
             skips.append(x)
     x = resnet(w, "mid_block.resnets.0.", x, temb, G, eps)
-    x = transformer(w, "mid_block.attentions.0.", x, ctx, heads, G)
+    x = transformer(w, "mid_block.attentions.0.", x, ctx, heads_at(len(ch) - 1), G)
     x = resnet(w, "mid_block.resnets.1.", x, temb, G, eps)
     attn_rev = list(reversed(arch.down_block_attn))
     for i in range(len(ch)):
@@ -114,7 +123,7 @@ def unet_forward(w: Dict, arch, sample: torch.Tensor, t, ctx: torch.Tensor) -> t
             x = torch.cat([x, skips.pop()], dim=1)
             x = resnet(w, f"up_blocks.{i}.resnets.{j}.", x, temb, G, eps)
             if attn_rev[i]:
-                x = transformer(w, f"up_blocks.{i}.attentions.{j}.", x, ctx, heads, G)
+                x = transformer(w, f"up_blocks.{i}.attentions.{j}.", x, ctx, heads_at(len(ch) - 1 - i), G)
         if i != len(ch) - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
             x = F.conv2d(x, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], w[f"up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
@@ -163,6 +172,7 @@ class PNDMOracle:
         self.final_alpha_cumprod = self.alphas_cumprod[0]          # set_alpha_to_one = False
         self.T = arch.num_train_timesteps
         self.offset = arch.steps_offset
+        self.v_prediction = getattr(arch, "prediction_type", "epsilon") == "v_prediction"
 
     def set_timesteps(self, n: int) -> List[int]:
         self.n = n
@@ -179,6 +189,8 @@ class PNDMOracle:
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t, b_prev = 1 - a_t, 1 - a_prev
+        if self.v_prediction:                                   # PNDMScheduler._get_prev_sample, prediction_type "v_prediction"
+            eps = (a_t ** 0.5) * eps + (b_t ** 0.5) * sample
         sample_coeff = (a_prev / a_t) ** 0.5
         denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
         return sample_coeff * sample - (a_prev - a_t) * eps / denom

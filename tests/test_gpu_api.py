@@ -143,7 +143,7 @@ def test_process_single_from_a_four_thread_pool(pkg, clip, images):
     pipe.retriever.build_image_index(pkg.synth.make_images(64, 64, seed=9))
     defense = pkg.MultiModalDefenseDetector(clip, config=pkg.DetectionConfig(text_variant_count=3, adaptive_threshold=False))
     defense.set_reference_bank(torch.nn.functional.normalize(torch.randn((500, 128), generator=torch.Generator().manual_seed(2)), dim=-1).cuda())
-    jobs = [(i % 6, (i * 5) % 6) for i in range(48)]                      # (image, text) pairs, mismatched ones included
+    jobs = [(i % 6, (i + i // 6) % 6) for i in range(48)]                 # (image, text) pairs: all 36 combinations, some twice
 
     def one(job):
         im, tx = job

@@ -392,3 +392,118 @@ def test_stable_diffusion_model_full_pipeline_toy_geometry_vs_oracle(pkg, tmp_pa
     a1 = torch.from_numpy(np.asarray(out.images[0], dtype=np.float32) / 255.0).permute(2, 0, 1)
     assert (a1 - imgs[1]).abs().max().item() < 0.5 / 255 + 1e-6
     clip.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Stable Diffusion 2.x geometry (BASELINE configs[4] names "SD-2.1"; the reference lists it as supported,
+# src/__init__.py:110-113, while every default it holds is SD-1.5): per-level head counts 5 / 10 / 20 / 20 at head dim 64,
+# linear proj_in / proj_out, cross-attention onto 1024-wide text states, optional v-prediction, an erf-GELU text tower.
+# Oracle: oracle/sd_oracle.py on the same weights -- PARITY UNPINNED, as for SD-1.5 (see its header).
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sd2(pkg):
+    arch = pkg.SDArch.sd21_base()
+    uw, _ = pkg.make_sd_weights(arch, seed=1, which="unet")
+    eng = pkg.TVCEngine()
+    k = pkg.SDKernels(eng, arch, uw, None)
+    yield arch, uw, k
+    eng.close()
+
+
+def test_sd21_geometry_and_parameter_count(pkg):
+    from importlib import import_module
+    import math
+    sa = import_module(pkg.__name__ + ".sd_arch")
+    a = pkg.SDArch.sd21_base()
+    assert [a.heads_at(i) for i in range(4)] == [5, 10, 20, 20] and all(c // a.heads_at(i) == 64 for i, c in enumerate(a.block_out_channels))
+    # the published size of stable-diffusion-2-1's UNet (865.9 M parameters) pins names and shapes, as 859.5 M does for SD-1.5
+    assert sum(math.prod(s) for _, s in sa.unet_param_shapes(a)) == 865_910_724
+    assert sum(math.prod(s) for _, s in sa.unet_param_shapes(pkg.SDArch.sd15())) == 859_520_964
+    assert dict(sa.unet_param_shapes(a))["down_blocks.0.attentions.0.proj_in.weight"] == (320, 320)           # nn.Linear
+    assert pkg.get_arch("SD2-text").text.act == "gelu" and pkg.get_arch("SD2-text").text.width == a.cross_attention_dim
+
+
+@pytest.mark.parametrize("prefix,c,hw,level", [("down_blocks.0.attentions.0.", 320, 32, 0), ("down_blocks.1.attentions.1.", 640, 16, 1),
+                                               ("up_blocks.1.attentions.2.", 1280, 8, 2), ("mid_block.attentions.0.", 1280, 8, 3)])
+def test_sd21_transformer_block_vs_oracle(pkg, sd2, prefix, c, hw, level):
+    arch, uw, k = sd2
+    g = torch.Generator().manual_seed(c + level)
+    x = torch.randn((2, c, hw, hw), generator=g)
+    ctx = torch.randn((2, arch.ctx, arch.cross_attention_dim), generator=g)
+    got = k.block(1, prefix, x, c, ctx=ctx)
+    with torch.no_grad():
+        ref = sd_oracle.transformer(uw, prefix, x, ctx, arch.heads_at(level), arch.norm_groups)
+    r2, rm = rel(got, ref)
+    print(f"[measured] SD-2.1 transformer {prefix} ({arch.heads_at(level)} heads of 64, linear projections, ctx 1024): rel L2 {r2:.2e} max|d|/std {rm:.2e}")
+    assert r2 < 7e-3 and rm < 6e-2           # the SD-1.5 blocks' bound (measured there 3.4e-3 / 2.0e-2 .. 2.6e-2)
+
+
+def test_sd21_unet_forward_vs_oracle(pkg, sd2):
+    arch, uw, k = sd2
+    g = torch.Generator().manual_seed(24)
+    lat = torch.randn((2, 4, 16, 16), generator=g)
+    ctx = torch.randn((2, arch.ctx, arch.cross_attention_dim), generator=g)
+    got = k.unet(lat, 701.0, ctx)
+    with torch.no_grad():
+        ref = sd_oracle.unet_forward(uw, arch, lat, 701, ctx)
+    r2, rm = rel(got, ref)
+    print(f"[measured] SD-2.1 UNet forward (16 x 16 latents, t = 701): rel L2 {r2:.2e} max|d|/std {rm:.2e}")
+    assert torch.isfinite(got).all() and r2 < 2.5e-2 and rm < 1e-1
+
+
+def test_v_prediction_sampling_loop_vs_oracle(pkg):
+    """prediction_type "v_prediction" (stable-diffusion-2-1 at 768 px): PNDMScheduler._get_prev_sample turns the combined
+    model output into sqrt(a_t) v + sqrt(b_t) x before the update -- folded into the two coefficients of the update kernel
+    (tvc_sd.cpp).  Toy geometry with per-level head counts, 6 steps, guidance 6, against the oracle's scheduler."""
+    arch = pkg.SDArch(block_out_channels=(64, 128), down_block_attn=(True, True), layers_per_block=1, heads=8, heads_per_block=(1, 2),
+                      linear_projection=True, prediction_type="v_prediction", cross_attention_dim=128,
+                      vae_block_out_channels=(64, 128), vae_layers_per_block=1, sample_size=16)
+    uw, vw = pkg.make_sd_weights(arch, seed=4)
+    eng = pkg.TVCEngine()
+    k = pkg.SDKernels(eng, arch, uw, vw)
+    g = torch.Generator().manual_seed(26)
+    n, steps, guidance = 2, 6, 6.0
+    cond, uncond = (torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g) for _ in range(2))
+    lat0 = torch.randn((n, 4, 16, 16), generator=g)
+    lat, img = k.generate(cond, uncond, lat0, steps, guidance, decode=True)
+    with torch.no_grad():
+        ref = sd_oracle.generate(uw, vw, arch, cond, uncond, lat0, steps, guidance, return_latents=True)
+        arch_eps = pkg.SDArch(**{**arch.__dict__, "prediction_type": "epsilon"})
+        ref_eps = sd_oracle.generate(uw, vw, arch_eps, cond, uncond, lat0, steps, guidance, return_latents=True)
+    r2, rm = rel(lat, ref)
+    print(f"[measured] v-prediction sampling loop, {steps} PLMS steps: final latents rel L2 {r2:.2e} max|d|/std {rm:.2e} "
+          f"(an epsilon-prediction loop on the same weights differs by {rel(ref_eps, ref)[0]:.2f})")
+    assert torch.isfinite(lat).all() and r2 < 3e-2 and rel(ref_eps, ref)[0] > 0.1
+    assert img.shape == (n, 3, 32, 32)
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "split", "fp32"])
+def test_erf_gelu_text_tower_vs_oracle(pkg, precision):
+    """The SD-2.x text encoder is OpenCLIP ViT-H/14's text tower: exact erf GELU instead of QuickGELU (TVC_ACT_GELU: a
+    store-only FC1 followed by a row kernel).  Toy geometry "ViT-T/16-gelu-test", hidden states (what conditions the UNet)
+    and pooled embeddings, in all three tower precisions."""
+    from oracle import clip_oracle
+    arch = pkg.get_arch("ViT-T/16-gelu-test")
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    eng = pkg.TVCEngine(arch, vw, tw, precision=precision)
+    toks = pkg.synth.make_tokens(3, 2, arch.ctx, seed=2).view(-1, arch.ctx)
+    imgs = pkg.synth.make_images(3, arch.image_size, seed=1)
+    hid = eng.encode_text_hidden(toks.cuda()).cpu()
+    ft = eng.encode_text(toks.cuda(), group=3).cpu()
+    fi = eng.encode_image(imgs.cuda()).cpu()
+    with torch.no_grad():
+        rh = clip_oracle.text_hidden(tw, toks.long(), arch.text.heads, act="gelu")
+        rt = clip_oracle.text_forward(tw, toks.long(), arch.text.heads, act="gelu")
+        ri = clip_oracle.vision_forward(vw, imgs, arch.vision.heads, arch.patch, act="gelu")
+        rq = clip_oracle.text_forward(tw, toks.long(), arch.text.heads, act="quick_gelu")
+    dh, dt, di = (hid - rh).abs().max().item(), (ft - rt).abs().max().item(), (fi - ri).abs().max().item()
+    print(f"[measured] erf-GELU towers, {precision}: hidden max|d| {dh:.2e}  text max|d| {dt:.2e}  image max|d| {di:.2e}  "
+          f"(QuickGELU on the same weights differs by {(rq - rt).abs().max().item():.2e})")
+    bound = 3e-3 if precision == "bf16" else 5e-5
+    assert dt < bound and di < bound and dh < (6e-2 if precision == "bf16" else 2e-4)
+    assert (rq - rt).abs().max().item() > 10 * bound            # the activation really matters at this tolerance
+    if precision == "bf16":
+        with pytest.raises(pkg.TVCError):                       # no backward pass for erf-GELU towers
+            eng.encode_image_grad(imgs.cuda(), True)
+    eng.close()

@@ -542,7 +542,8 @@ int tvc_topk_merge(tvc_handle* h, const int32_t* idx_parts_dev, const float* sim
     if (!h) return TVC_E_INVALID;
     if (M < 0 || !idx_parts_dev || !sim_parts_dev || !idx_out_dev || !sim_out_dev)
         return fail(h, TVC_E_INVALID, "tvc_topk_merge: bad arguments");
-    if (W < 1 || k < 1 || k > TVC_MAX_TOPK || W * k > 256 || kf < 0 || kf > k || kf > 32 || D < 1 || (kf > 0 && feat_parts_dev && !feat_out_dev))
+    if (W < 1 || k < 1 || k > TVC_MAX_TOPK || W * k > 256 || kf < 0 || kf > k || kf > 32 ||
+        (kf > 0 && feat_parts_dev && (!feat_out_dev || D < 1)))
         return fail(h, TVC_E_INVALID, "tvc_topk_merge: limits are W * k <= 256, kf <= min(k, 32)");
     hipError_t st = launch_topk_merge(idx_parts_dev, sim_parts_dev, feat_parts_dev, mom_parts_dev, W, M, k, kf, D,
                                       idx_out_dev, sim_out_dev, feat_out_dev, mom_out_dev, (hipStream_t)stream);

@@ -70,6 +70,10 @@ struct Run {
         int64_t S = tiles0 > 0 ? 256 / tiles0 : 1;
         if (S > nk64 / 4) S = nk64 / 4;
         if (S > 16) S = 16;
+        // the split kernels run the one-tile loop at about half the ring kernel's rate: a two-way split of a shallow K
+        // (the 16 x 16 level's linear layers: 120 tiles x 20 K-tiles) loses to 120 ring workgroups (measured 418 against
+        // ~550 TFLOP/s); it pays from three ways on, or on a deep K (>= 32 K-tiles per slice)
+        if (S == 2 && nk64 / 2 < 32) S = 1;
         return S >= 2 ? (int)S : 1;
     }
     // launch with the fixed split; the fp32 partial tiles are scratch of the arena

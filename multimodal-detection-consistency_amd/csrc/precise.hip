@@ -7,6 +7,7 @@
 // slower than the bf16 towers and is not the benchmarked path).
 #include "common.hpp"
 #include "kernels.hpp"
+#include <mutex>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -224,13 +225,12 @@ hipError_t launch_attention_f32(const float* qkv, float* out, int n_seq, int T, 
     if (n_seq <= 0) return hipSuccess;
     if (T <= 0 || T > 288 || heads <= 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)T * 64 * 4 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024 - 512);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::once_flag attr_once;          // thread-safe: two engines may first-launch from two threads
+    static hipError_t attr_st = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_st = hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    });
+    if (attr_st != hipSuccess) return attr_st;
     hipLaunchKernelGGL(attention_f32_kernel, dim3(n_seq * heads), dim3(256), lds, stream, qkv, out, T, heads, causal);
     return hipGetLastError();
 }

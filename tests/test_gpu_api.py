@@ -327,6 +327,11 @@ def test_bench_gpus_flag_runs_two_ranks_on_one_gpu(pkg):
         assert len(lines) == 1
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 32
+        # what the process group itself reports (on an 8-GPU node: backend "nccl" = RCCL, world_size 8)
+        assert out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+        if "--shard-bank" in extra:
+            assert out["exchange"]["mode"] == "fused" and out["exchange"]["bytes_per_peer"] > 0 and "status_check" in out["exchange"]
+            assert "all_to_all_single" in out["distributed"]["data_path_collectives"]
 
 
 def test_text_variant_generator_clip_filter(pkg, clip):

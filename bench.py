@@ -627,8 +627,9 @@ def main():
             torch.cuda.synchronize(); lat.append(time.perf_counter() - t1)
         out["through_api"]["process_single_ms"] = round(sorted(lat[1:])[len(lat[1:]) // 2] * 1e3, 2)
         out["through_api"]["process_single_note"] = ("median of 5 calls, one query end to end (text variants + retrieval over the "
-                                                     f"{R}-row index + detection); the reference's README quotes ~50 ms per query for "
-                                                     "its CLIP-only path on its own hardware (README.md:896, context only)")
+                                                     f"{R}-row index + detection, no SD references); the reference's README quotes 19.1 ms "
+                                                     "P50 / 45.7 ms P99 per query and 52.3 queries/s for its full pipeline (Qwen + SD) on "
+                                                     "6 x RTX 4090 (README.md:890-898): other hardware and workload, context only")
 
     if extras:
         # ---- K5 in the HBM-bound regime of SURVEY.md 8(d): small query batches (the reference searches one query at a time,

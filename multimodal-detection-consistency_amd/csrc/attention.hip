@@ -17,6 +17,11 @@
 // statistics are per-lane scalars; a lane's output is 4 consecutive head dims per 16-wide tile, swapped between
 // neighbouring tiles (v_permlane16_swap) into 16-byte store pieces.
 //
+// A persistent form (item i + 1's K / V rows requested before item i's query blocks and written to LDS after them) was
+// built and measured in round 4 (git show 410b4a7:multimodal-detection-consistency_amd/csrc/attention.hip; EXPERIMENTS.md): bit-identical,
+// 365-400 us against 277-292 us per ViT-L/14 layer call -- its 72 staging registers leave room for 0-4 pinned K tiles instead
+// of 15 and the block loop becomes LDS-bound.
+//
 // What bounds it (in-kernel clock stamps, round 3): the memory system's rate on the packed rows' 128-byte
 // per-head pieces, not vector issue.  Hence the XCD-contiguous item order, the unconditional one-latency fill, the wait
 // for the next block's Q fragments placed BEFORE the block's stores (vmcnt counts stores), and the 16-byte stores.
@@ -328,189 +333,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent form for the vision tower (fixed-length, non-causal, every query: the EXACT case above; experiment of round
-// 4, TVC_ATT_PERSIST): a workgroup walks items j * gridDim + wg (neighbouring workgroups of an XCD work on adjacent heads
-// of the same sequences in the same round, as the one-item kernel's XCD-contiguous order arranges), and the K / V rows of
-// item j + 1 are REQUESTED before item j's query blocks start and written to LDS after they end: the fill's memory
-// latency (a quarter to a third of an item's life in the one-item kernel) runs under the blocks.  The 72 staging
-// registers are paid for by pinning KPIN = 6 instead of 15 K tiles (the others are re-read from LDS per block).
-// Same arithmetic in the same order per output element: bit-identical to attention_kernel<MAXT, false, 4, true>.
-// ---------------------------------------------------------------------------------------------------------------
-template <int MAXT, int KPIN>
-__global__ __launch_bounds__(256, 2) void attention_persist_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                                   int T, int heads, int n_items, int k_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int width = heads * ATT_DH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
-    constexpr int NT = MAXT, KT = NT * 16, VT = NT * 16;
-    char* ldsK = smem;
-    char* ldsV = ldsK + k_bytes;
-    const int64_t ld = 3 * (int64_t)width;
-    const int g = lane >> 4, r16 = lane & 15;
-    const int sw0 = ((0 + g) ^ ((lane >> 1) & 7)) << 4;
-    const int sw1 = ((4 + g) ^ ((lane >> 1) & 7)) << 4;
-    const int tr_off = (4 * g + (r16 >> 2)) * ATT_VROW + ((r16 & 3) << 3);
-    const float scale_log2 = 0.125f * 1.4426950408889634f;
-    const int NQ = (T + 15) >> 4;
-    f32x4_t pen_tail;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pen_tail[r] = ((NT - 1) * 16 + 4 * g + r >= T) ? -INFINITY : 0.f;
-
-    constexpr int KIT = (MAXT * 16 * 8 + 255) / 256;
-    u32x4_t kv[KIT], vv[KIT];
-    auto issue_fill = [&](int item) __attribute__((always_inline)) {
-        const int seq = item / heads, h = item - seq * heads;
-        const uint16_t* base = qkv + (int64_t)seq * T * ld + h * ATT_DH;
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int idx = tid + i * 256;
-            const int key = idx >> 3, c = idx & 7;
-            const uint16_t* p = base + (int64_t)(key < T ? key : T - 1) * ld + c * 8;
-            kv[i] = ATT_LD_KV((const u32x4_t*)(p + width));
-            vv[i] = ATT_LD_KV((const u32x4_t*)(p + 2 * width));
-        }
-    };
-    auto write_fill = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int idx = tid + i * 256;
-            const int key = idx >> 3, c = idx & 7;
-            if (idx < KT * 8) {
-                *(u32x4_t*)(ldsK + key * ATT_KROW + ((c ^ ((key >> 1) & 7)) << 4)) = key < T ? kv[i] : u32x4_t{0u, 0u, 0u, 0u};
-                *(u32x4_t*)(ldsV + key * ATT_VROW + (c << 4)) = key < T ? vv[i] : u32x4_t{0u, 0u, 0u, 0u};
-            }
-        }
-    };
-    int item = wg;
-    if (item < n_items) issue_fill(item);
-    for (; item < n_items; item += gridDim.x) {
-        const int seq = item / heads, h = item - seq * heads;
-        const int64_t row0 = (int64_t)seq * T;
-        auto q_ptr = [&](int qb) {
-            int qrow = qb * 16 + r16;
-            qrow = qrow < T ? qrow : T - 1;
-            return qkv + (row0 + qrow) * ld + h * ATT_DH + 8 * g;
-        };
-        bf16x8_t nq0 = {}, nq1 = {};
-        if (wave < NQ) { const uint16_t* qp = q_ptr(wave); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
-        write_fill();
-        __syncthreads();
-        if (item + (int)gridDim.x < n_items) issue_fill(item + gridDim.x);      // in flight during this item's blocks
-        bf16x8_t ka[KPIN > 0 ? KPIN : 1], kb[KPIN > 0 ? KPIN : 1];
-#pragma unroll
-        for (int t = 0; t < KPIN; ++t) {
-            ka[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw0);
-            kb[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw1);
-        }
-        for (int qb = wave; qb < NQ; qb += 4) {
-            const int qr = qb * 16 + r16;
-            const bf16x8_t bq0 = nq0, bq1 = nq1;
-            if (qb + 4 < NQ) { const uint16_t* qp = q_ptr(qb + 4); nq0 = ATT_LD_Q((const bf16x8_t*)qp); nq1 = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
-            int zoff = 0;
-            asm volatile("" : "+v"(zoff));
-            const char* ldsK_i = ldsK + zoff;
-            f32x4_t s[MAXT];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const f32x4_t c0 = (t == MAXT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                const bf16x8_t a0 = t < KPIN ? ka[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, c0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const bf16x8_t a1 = t < KPIN ? kb[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw1);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, s[t], 0, 0, 0);
-            }
-            float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                m0 = __builtin_elementwise_maximum(m0, __builtin_elementwise_maximum(s[t][0], s[t][1]));
-                m1 = __builtin_elementwise_maximum(m1, __builtin_elementwise_maximum(s[t][2], s[t][3]));
-            }
-            float mx = __builtin_elementwise_maximum(m0, m1);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mxs = mx * scale_log2;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2, -mxs));
-            f32x4_t osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-            f32x4_t o[4];
-#pragma unroll
-            for (int md = 0; md < 4; ++md) o[md] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < (MAXT + 1) / 2; ++u) {
-                const int t0 = 2 * u, t1 = 2 * u + 1;
-                const f32x4_t p0 = s[t0];
-                const f32x4_t p1 = (t1 < MAXT) ? s[t1 < MAXT ? t1 : 0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                u32x4_t pk;
-                pk[0] = pack_bf16x2(p0[0], p0[1]);
-                pk[1] = pack_bf16x2(p0[2], p0[3]);
-                pk[2] = pack_bf16x2(p1[0], p1[1]);
-                pk[3] = pack_bf16x2(p1[2], p1[3]);
-                const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pk);
-#pragma unroll
-                for (int md = 0; md < 4; ++md) {
-                    const char* vb = ldsV + tr_off + md * 32;
-                    const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vb + t0 * 16 * ATT_VROW));
-                    const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vb + (t1 >= MAXT ? t0 : t1) * 16 * ATT_VROW));
-                    bf16x8_t a;
-                    a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3];
-                    a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
-                    o[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, o[md], 0, 0, 0);
-                }
-                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, osum, 0, 0, 0);
-            }
-            asm volatile("" : "+v"(nq0), "+v"(nq1));
-            const float inv = 1.0f / osum[0];
-            u32x4_t ow[2];
-#pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {
-                const f32x4_t v0 = o[2 * mp] * inv, v1 = o[2 * mp + 1] * inv;
-                const auto r0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-                ow[mp][0] = r0[0]; ow[mp][1] = r1[0]; ow[mp][2] = r0[1]; ow[mp][3] = r1[1];
-            }
-            if (qr < T) {
-                uint16_t* op = out + (row0 + qr) * (int64_t)width + h * ATT_DH + (g & 1) * 16 + (g >> 1) * 8;
-                ATT_ST_O((u32x4_t*)op, ow[0]);
-                ATT_ST_O((u32x4_t*)(op + 32), ow[1]);
-            }
-        }
-        __syncthreads();            // every wave is done with this item's K / V images before the next item overwrites them
-    }
-}
-
-#ifndef TVC_ATT_PERSIST
-#define TVC_ATT_PERSIST 0           // 0: one item per workgroup (the product); 1: the persistent form (experiment)
-#endif
-#ifndef TVC_ATT_KPIN
-#define TVC_ATT_KPIN 2              // K tiles the persistent form keeps in registers (each costs 8 VGPRs next to 72 staging registers)
-#endif
-template <int MAXT>
-static hipError_t launch_persist(const uint16_t* qkv, uint16_t* out, int n_seq, int T, int heads, hipStream_t stream) {
-    constexpr int KP = TVC_ATT_KPIN > MAXT ? MAXT : TVC_ATT_KPIN;
-    const int k_bytes = MAXT * 16 * ATT_KROW;
-    const size_t lds = (size_t)k_bytes + (size_t)MAXT * 16 * ATT_VROW;
-    static std::once_flag attr_once;
-    static hipError_t attr_st = hipSuccess;
-    std::call_once(attr_once, [] {
-        attr_st = hipFuncSetAttribute((const void*)attention_persist_kernel<MAXT, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    });
-    if (attr_st != hipSuccess) return attr_st;
-    const int n_items = n_seq * heads;
-    const int grid = n_items < 512 ? n_items : 512;          // two workgroups per CU, each walking items wg, wg + 512, ...
-    hipLaunchKernelGGL((attention_persist_kernel<MAXT, KP>), dim3(grid), dim3(256), lds, stream, qkv, out, T, heads, n_items, k_bytes);
-    return hipGetLastError();
-}
-
 template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
                              int max_T, int heads, hipStream_t stream, const int32_t* pfx = nullptr,
@@ -553,7 +375,6 @@ hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* s
         if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
         return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
     }
-    if (TVC_ATT_PERSIST > 0 && !starts && NT == 17 && pool_mode == 0) return launch_persist<17>(qkv, out, n_seq, seq_len, heads, stream);
     if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);   // ViT-L/14: 257 tokens
     if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);     // ViT-B/32: 50 tokens
     if (NT <= 2) return launch_one<2, false, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);

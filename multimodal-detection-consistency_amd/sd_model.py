@@ -255,7 +255,7 @@ class StableDiffusionModel:
             else:
                 logger.warning("latent-diffusion model '%s': seeded RANDOM UNet / VAE weights (random_init=True) -- its images "
                                "are noise; for benchmarks and parity tests only", self.config.model_name)
-                weights = make_sd_weights(self.arch, self.config.seed)
+                weights = make_sd_weights(self.arch, self.config.seed, device=str(self.device))
         self.kernels = SDKernels(self.text_engine, self.arch, weights[0], weights[1])
         self.generation_count = 0
 

@@ -28,7 +28,7 @@ def rel(got: torch.Tensor, ref: torch.Tensor):
 @pytest.fixture(scope="module")
 def sd(pkg):
     arch = pkg.SDArch()
-    uw, vw = pkg.make_sd_weights(arch, seed=0)
+    uw, vw = pkg.make_sd_weights(arch, seed=0, device="cuda")          # 0.9 G parameters: drawn on the device, kept on the host
     eng = pkg.TVCEngine()
     k = pkg.SDKernels(eng, arch, uw, vw)
     yield arch, uw, vw, k
@@ -181,14 +181,14 @@ def test_sampling_loop_vs_oracle(pkg, sd):
     n, steps, guidance = 2, 5, 7.5
     cond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
     uncond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
-    lat0 = torch.randn((n, 4, 16, 16), generator=g)
+    lat0 = torch.randn((n, 4, 8, 8), generator=g)            # 8 x 8 latents: the smallest size the four-level UNet takes
     lat, img = k.generate(cond, uncond, lat0, steps, guidance, decode=True)
     with torch.no_grad():
         ref = sd_oracle.generate(uw, vw, arch, cond, uncond, lat0, steps, guidance, return_latents=True)
     r2, rm = rel(lat, ref)
     print(f"[measured] sampling loop, {steps} PLMS steps, guidance {guidance}: final latents rel L2 {r2:.2e} max|d|/std {rm:.2e}")
-    assert torch.isfinite(lat).all() and r2 < 3e-2           # measured 1.35e-2
-    assert img.shape == (n, 3, 128, 128) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert torch.isfinite(lat).all() and r2 < 3e-2           # measured 1.35e-2 (16 x 16 latents, round 3)
+    assert img.shape == (n, 3, 64, 64) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
     # the scheduler arithmetic alone (same eps on both sides would be exact): timesteps visited
     sch = sd_oracle.PNDMOracle(arch)
     assert sch.set_timesteps(steps) == [801, 601, 601, 401, 201, 1]
@@ -196,14 +196,15 @@ def test_sampling_loop_vs_oracle(pkg, sd):
 
 def test_sampling_loop_20_steps_vs_oracle(pkg, sd):
     """The reference's fast setting (experiments/defenses/generative_ref.py: 20 steps; src/sd_ref.py:226-230 defaults to
-    50): 20 PLMS steps = 21 UNet evaluations with guidance 7.5 at 16 x 16 latents, one image.  The deviation of the final
-    latents is MEASURED (printed) and bounded at ~2x: bf16 activations inside a 21-evaluation feedback loop."""
+    50): 20 PLMS steps = 21 UNet evaluations with guidance 7.5 at 8 x 8 latents (the CPU oracle's 21 evaluations of the full
+    SD-1.5 UNet take 70 s at 16 x 16), one image.  The deviation of the final latents is MEASURED (printed) and bounded at
+    ~2x: bf16 activations inside a 21-evaluation feedback loop (8.9e-3 at 16 x 16 latents, gpurun_out/r04_t1.log)."""
     arch, uw, vw, k = sd
     g = torch.Generator().manual_seed(16)
     n, steps, guidance = 1, 20, 7.5
     cond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
     uncond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
-    lat0 = torch.randn((n, 4, 16, 16), generator=g)
+    lat0 = torch.randn((n, 4, 8, 8), generator=g)
     lat, _ = k.generate(cond, uncond, lat0, steps, guidance, decode=False)
     with torch.no_grad():
         ref = sd_oracle.generate(uw, vw, arch, cond, uncond, lat0, steps, guidance, return_latents=True)
@@ -403,7 +404,7 @@ def test_stable_diffusion_model_full_pipeline_toy_geometry_vs_oracle(pkg, tmp_pa
 @pytest.fixture(scope="module")
 def sd2(pkg):
     arch = pkg.SDArch.sd21_base()
-    uw, _ = pkg.make_sd_weights(arch, seed=1, which="unet")
+    uw, _ = pkg.make_sd_weights(arch, seed=1, which="unet", device="cuda")
     eng = pkg.TVCEngine()
     k = pkg.SDKernels(eng, arch, uw, None)
     yield arch, uw, k

@@ -833,6 +833,21 @@ def main():
                                "sample": f"{done} queries of the same workload in {secs:.1f}s, oracle "
                                          f"(PyTorch-CPU fp32 towers + numpy scores), de-duplicated schedule"}
         out["speedup_vs_cpu"] = round(out["value"] / v, 1) if v > 0 else None
+        if extras and "sd_reference" in out:
+            # BASELINE configs[4]'s AUROC leg: the three-method defence (text variants + GENERATED references + consistency) on
+            # PGD-perturbed inputs, HIP against the CPU oracle (oracle/defence_check.py: the checker, at a geometry the oracle
+            # finishes in ~20 s; tests/test_gpu_auroc.py asserts the same check at Q = 128)
+            from oracle import defence_check
+            t_a = time.perf_counter()
+            dc = defence_check.three_method_auroc(pkg, Q=64, N=4, J=2, steps=3)
+            out["sd_reference"]["auroc_delta"] = round(dc["auroc_gpu"] - dc["auroc_oracle"], 5)
+            out["sd_reference"]["auroc_check"] = {"auroc_gpu": round(dc["auroc_gpu"], 4), "auroc_oracle": round(dc["auroc_oracle"], 4),
+                                                  "max_abs_aggregated_score_dev": float(f"{dc['max_abs_aggregated_dev']:.3g}"),
+                                                  "queries": dc["Q"], "references_per_query": dc["references_per_query"],
+                                                  "seconds": round(time.perf_counter() - t_a, 1),
+                                                  "note": "toy CLIP + two-level latent-diffusion geometry, half the queries perturbed by the "
+                                                          "in-tree PGDAttacker, references generated on both sides from the same prompts / seeds; "
+                                                          "bar +-0.002 (the SD oracle is parity-unpinned)"}
         if extras:
             more = {}
             v2, d2, s2 = cpu_baseline(arch, weights, img_c, tok_c, bank_cpu, 12.0, cores, schedule="reference", max_queries=4)

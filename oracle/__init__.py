@@ -22,4 +22,9 @@ Pinning status
   at that boundary.  The restatement follows the
   published OpenAI-CLIP architecture and is cross-checked against
   ``transformers.CLIPModel`` built from a local config (no download).
+* ``sd_oracle`` (UNet2DConditionModel / AutoencoderKL.decode / PNDM loop, SD-1.5 and SD-2.x geometry) is **parity
+  unpinned and cross-checked against nothing** (``diffusers`` is not importable, weights and vectors are absent); its
+  parameter inventories reproduce the published parameter counts of both UNets.
+* ``defence_check`` drives the PRODUCT's public API and the oracles above side by side (the three-method defence on PGD
+  inputs: ``tests/test_gpu_auroc.py``, and ``sd_reference.auroc_delta`` in the ``cpu_baseline`` leg of ``bench.py``).
 """

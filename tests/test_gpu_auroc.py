@@ -101,90 +101,21 @@ def test_auroc_q1000_vit_b32_committed_pgd_fixture(pkg):
     eng.close()
 
 
-def _captions(n: int, seed: int = 0):
-    """n distinct synthetic captions (COCO-shaped: 6..12 words)."""
-    import random
-    rnd = random.Random(seed)
-    nouns = ["dog", "cat", "man", "woman", "child", "car", "bus", "train", "horse", "bird", "table", "pizza", "kite", "boat", "bench"]
-    verbs = ["sitting on", "standing near", "running past", "looking at", "holding", "riding", "jumping over", "next to"]
-    adjs = ["red", "small", "large", "old", "wooden", "bright", "two", "several", "young", "white"]
-    places = ["in a park", "on the beach", "in a kitchen", "on a city street", "at night", "in the snow", "near a lake", "indoors"]
-    out, seen = [], set()
-    while len(out) < n:
-        c = f"a {rnd.choice(adjs)} {rnd.choice(nouns)} {rnd.choice(verbs)} a {rnd.choice(adjs)} {rnd.choice(nouns)} {rnd.choice(places)}"
-        if c not in seen:
-            seen.add(c); out.append(c)
-    return out
-
-
 def test_auroc_three_method_defence_with_generated_sd_references_on_pgd_inputs(pkg):
-    """BASELINE configs[4] at the toy geometry: Q = 128 queries (64 clean, 64 perturbed by the in-tree PGDAttacker --
-    the SAME pixels go to both sides), N = 4 template variants, 2 generated references per query (3 PLMS steps + CFG,
-    16 x 16 latents -> 32 x 32 pixels -> CLIP preprocess -> image tower).  HIP: AdversarialDetector.batch_detect with the
-    in-tree SDReferenceGenerator; oracle: clip_oracle towers, sd_oracle.generate from the same prompts / seeds / noise,
-    tvc_oracle.detect_adversarial_src(sd_ref_feats=...).  Bar: |dAUROC| <= 0.002 (BASELINE.json)."""
-    from oracle import sd_oracle
-    F = torch.nn.functional
-    carch = pkg.get_arch("ViT-T/16-test")
-    cw = pkg.synth.make_clip_weights(carch, seed=0)
-    sarch = pkg.SDArch(block_out_channels=(64, 128), down_block_attn=(True, False), layers_per_block=1, heads=8,
-                       cross_attention_dim=128, vae_block_out_channels=(64, 128), vae_layers_per_block=1, sample_size=16)
-    uw, vw = pkg.make_sd_weights(sarch, seed=3)
-    Q, N, J, steps, guidance, px = 128, 4, 2, 3, 5.0, 32
-    half = Q // 2
-    texts = _captions(Q)
-    variants = pkg.variants.batch_variants(None, N, texts)
-    clip = pkg.CLIPModel(pkg.CLIPConfig(model_name=carch.name), weights=cw)
-    sdm = pkg.StableDiffusionModel(pkg.SDModelConfig(), clip_model=clip, arch=sarch, weights=(uw, vw))
-    gen = pkg.SDReferenceGenerator(pkg.SDReferenceConfig(num_images_per_prompt=J, num_inference_steps=steps, guidance_scale=guidance,
-                                                         height=px, width=px, use_text_variants=False, filter_low_quality=False,
-                                                         enable_cache=False), sd_model=sdm, clip_model=clip)
-    clean = pkg.synth.make_images(Q, carch.image_size, seed=1)
-    atk = pkg.PGDAttacker(clip, pkg.PGDAttackConfig(batch_size=half, random_seed=7))
-    adv = atk.perturb(clean[half:].cuda(), texts[half:]).cpu()
-    images = torch.cat([clean[:half], adv])
-    labels = np.r_[np.zeros(half), np.ones(half)]
-    methods = ["text_variants", "sd_reference", "consistency"]
-    det = pkg.AdversarialDetector(pkg.DetectorConfig(clip_model=carch.name, num_text_variants=N, num_reference_images=J),
-                                  clip_model=clip, sd_generator=gen)
-    res = det.batch_detect(images.cuda(), texts, methods=methods, variants=variants)
-    got = np.array([r["aggregated_score"] for r in res])
-    got_sd = np.array([r["detection_scores"]["sd_reference"] for r in res])
-    assert all(r["detection_details"]["sd_reference"]["num_references"] == J for r in res)
-    # ---- CPU oracle: towers, generated references, reference arithmetic
-    flat = [t for i in range(Q) for t in [texts[i]] + list(variants[i])]
-    with torch.no_grad():
-        fi = clip_oracle.vision_forward(cw[0], images, carch.vision.heads, carch.patch).numpy()
-        ft = clip_oracle.text_forward(cw[1], clip.tokenize(flat), carch.text.heads).view(Q, N + 1, -1).numpy()
-        cond = clip_oracle.text_hidden(cw[1], sdm.tokenize(texts).long(), carch.text.heads)
-        unc = clip_oracle.text_hidden(cw[1], sdm.tokenize([""]).long(), carch.text.heads)
-        seeds = gen._generate_seeds(J)
-        up = 2 ** (len(sarch.vae_block_out_channels) - 1)
-        refs = []
-        for i0 in range(0, Q, 32):                                   # 32 prompts x J seeds per oracle pass
-            c = cond[i0:i0 + 32].repeat_interleave(J, 0)
-            lat0 = sdm.initial_latents(seeds * (c.shape[0] // J), sarch.in_channels, px // up, px // up)
-            refs.append(sd_oracle.generate(uw, vw, sarch, c, unc.expand(c.shape[0], -1, -1), lat0, steps, guidance))
-        refs = torch.cat(refs)                                       # [Q * J, 3, 32, 32] in [0, 1]
-        S = carch.image_size                                         # CLIP preprocess (clip.preprocess_tensor): bicubic, crop, mean / std
-        r = F.interpolate(refs, size=(S, S), mode="bicubic", antialias=True, align_corners=False)
-        mean = torch.tensor((0.48145466, 0.4578275, 0.40821073)).view(1, 3, 1, 1)
-        std = torch.tensor((0.26862954, 0.26130258, 0.27577711)).view(1, 3, 1, 1)
-        fr = clip_oracle.vision_forward(cw[0], (r - mean) / std, carch.vision.heads, carch.patch).view(Q, J, -1).numpy()
-    ref_res = [tvc_oracle.detect_adversarial_src(fi[i], ft[i], methods=methods, sd_ref_feats=fr[i]) for i in range(Q)]
-    ref = np.array([r["aggregated_score"] for r in ref_res])
-    ref_sd = np.array([r["detection_scores"]["sd_reference"] for r in ref_res])
-    auc_ref = tvc_oracle.detection_metrics(ref, labels)["auc"]
-    auc_gpu = tvc_oracle.detection_metrics(got, labels)["auc"]
-    auc_sd_ref = tvc_oracle.detection_metrics(ref_sd, labels)["auc"]
-    auc_sd_gpu = tvc_oracle.detection_metrics(got_sd, labels)["auc"]
-    d_agg, d_sd = np.abs(got - ref), np.abs(got_sd - ref_sd)
-    print(f"[measured] three-method defence, Q={Q}: AUROC oracle {auc_ref:.4f} gpu {auc_gpu:.4f} (sd_reference alone: "
-          f"{auc_sd_ref:.4f} / {auc_sd_gpu:.4f}); |d aggregated_score| max {d_agg.max():.2e} median {np.median(d_agg):.2e}; "
-          f"|d sd_reference| max {d_sd.max():.2e} median {np.median(d_sd):.2e}; score spread (std) {ref.std():.3f}")
-    assert abs(auc_gpu - auc_ref) <= 0.002
-    assert abs(auc_sd_gpu - auc_sd_ref) <= 0.002
-    assert d_agg.max() < 1.5e-3 and d_sd.max() < 1e-3               # measured 5.5e-4 / 3.1e-4 with 3 references x 4 steps (bf16 towers + bf16 UNet / VAE)
-    flip = np.array([r["is_adversarial"] for r in res]) != np.array([r["is_adversarial"] for r in ref_res])
-    assert (np.abs(ref[flip] - 0.5) < 1.5e-3).all()
-    clip.engine.close()
+    """BASELINE configs[4] at the toy geometry (oracle/defence_check.py): Q = 128 queries (64 clean, 64 perturbed by the
+    in-tree PGDAttacker -- the SAME pixels go to both sides), N = 4 template variants, 2 generated references per query
+    (3 PLMS steps + CFG, 16 x 16 latents -> 32 x 32 pixels -> CLIP preprocess -> image tower).  HIP:
+    AdversarialDetector.batch_detect with the in-tree SDReferenceGenerator; oracle: clip_oracle towers, sd_oracle.generate
+    from the same prompts / seeds / noise, tvc_oracle.detect_adversarial_src(sd_ref_feats=...).
+    Bar: |dAUROC| <= 0.002 (BASELINE.json).  bench.py reports the same check as sd_reference.auroc_delta."""
+    from oracle import defence_check
+    r = defence_check.three_method_auroc(pkg, Q=128, N=4, J=2, steps=3)
+    print(f"[measured] three-method defence, Q={r['Q']}: AUROC oracle {r['auroc_oracle']:.4f} gpu {r['auroc_gpu']:.4f} (sd_reference alone: "
+          f"{r['auroc_sd_oracle']:.4f} / {r['auroc_sd_gpu']:.4f}); |d aggregated_score| max {r['max_abs_aggregated_dev']:.2e} median "
+          f"{r['median_abs_aggregated_dev']:.2e}; |d sd_reference| max {r['max_abs_sd_reference_dev']:.2e}; score spread (std) {r['score_std']:.3f}")
+    assert all(n == 2 for n in r["num_references"])
+    assert abs(r["auroc_gpu"] - r["auroc_oracle"]) <= 0.002
+    assert abs(r["auroc_sd_gpu"] - r["auroc_sd_oracle"]) <= 0.002
+    # measured 5.5e-4 / 3.1e-4 with 3 references x 4 steps (bf16 towers + bf16 UNet / VAE)
+    assert r["max_abs_aggregated_dev"] < 1.5e-3 and r["max_abs_sd_reference_dev"] < 1e-3
+    assert r["max_flip_distance_to_threshold"] < 1.5e-3          # decisions differ only where the score sits on the threshold

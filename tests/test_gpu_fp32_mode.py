@@ -20,6 +20,7 @@ from oracle import clip_oracle, tvc_oracle
 
 pytestmark = pytest.mark.gpu
 
+_ORACLE_CACHE = {}
 EMB_BOUND = 5e-5        # per embedding component (L2-normalised rows: components ~ 1/sqrt(D))
 SCORE_BOUND = 1e-4      # BASELINE.json north_star
 
@@ -215,9 +216,12 @@ def test_fp32_mode_config2_step_8_queries_within_1e4(pkg, precision):
     rec = eng.consistency(fi, ft.view(B, N + 1, D), cfg, tidx.contiguous(), tsim.contiguous(), feat).cpu().numpy()
     assert np.isfinite(rec[:, :11]).all() and rec[:, 8].mean() > 1.0
     sub = np.linspace(0, B - 1, 8).astype(int)
-    with torch.no_grad():
-        ri = clip_oracle.vision_forward(vw, images[sub].cpu(), arch.vision.heads, arch.patch)
-        rt = clip_oracle.text_forward(tw, tokens[sub].reshape(-1, arch.ctx).cpu().long(), arch.text.heads).view(len(sub), N + 1, D)
+    if "config2" not in _ORACLE_CACHE:             # the fp32 CPU towers of the 8 queries: ~12 s, the same for both modes
+        with torch.no_grad():
+            _ORACLE_CACHE["config2"] = (
+                clip_oracle.vision_forward(vw, images[sub].cpu(), arch.vision.heads, arch.patch),
+                clip_oracle.text_forward(tw, tokens[sub].reshape(-1, arch.ctx).cpu().long(), arch.text.heads).view(len(sub), N + 1, D))
+    ri, rt = _ORACLE_CACHE["config2"]
     (ci, di), (ct, dt) = _dev(fi.cpu()[sub], ri), _dev(ft.view(B, N + 1, D).cpu()[sub].reshape(-1, D), rt.reshape(-1, D))
     ref = tvc_oracle.detect_batch(ri.numpy(), rt.numpy(), bank.float().cpu().numpy(),
                                   checker=tvc_oracle.ConsistencyCheckerOracle(adaptive_threshold=False))

@@ -836,10 +836,10 @@ def main():
         if extras and "sd_reference" in out:
             # BASELINE configs[4]'s AUROC leg: the three-method defence (text variants + GENERATED references + consistency) on
             # PGD-perturbed inputs, HIP against the CPU oracle (oracle/defence_check.py: the checker, at a geometry the oracle
-            # finishes in ~20 s; tests/test_gpu_auroc.py asserts the same check at Q = 128)
+            # finishes in ~10 s; tests/test_gpu_auroc.py asserts the same check)
             from oracle import defence_check
             t_a = time.perf_counter()
-            dc = defence_check.three_method_auroc(pkg, Q=64, N=4, J=2, steps=3)
+            dc = defence_check.three_method_auroc(pkg, Q=128, N=4, J=2, steps=3)
             out["sd_reference"]["auroc_delta"] = round(dc["auroc_gpu"] - dc["auroc_oracle"], 5)
             out["sd_reference"]["auroc_check"] = {"auroc_gpu": round(dc["auroc_gpu"], 4), "auroc_oracle": round(dc["auroc_oracle"], 4),
                                                   "max_abs_aggregated_score_dev": float(f"{dc['max_abs_aggregated_dev']:.3g}"),

@@ -196,37 +196,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
 
 
 // ---------------------------------------------------------------------------
-// Ring main loop, fourth form: barrier-staggered ping-pong in phases of 16 MFMAs (after the "256^2 8-phase"
-// recipe of /opt/skills/guides/cdna_hip_programming.md section 5, rebuilt here for a persistent tile stream).
+// Ring main loop, fifth form (round 4; "ring4" in the names is the kernel family): barrier-staggered ping-pong in phases of
+// 16 MFMAs after the "256^2 8-phase" recipe of /opt/skills/guides/cdna_hip_programming.md section 5, rebuilt for a
+// persistent tile stream.
 //
 //   * A K-tile (64 deep) is multiplied in FOUR phases, one quadrant (64 out-features x 32 tokens x K 64 = 16 MFMAs)
 //     of the wave's 128 x 64 sub-tile each: (Aq0,Bq0) (Aq0,Bq1) (Aq1,Bq1) (Aq1,Bq0).
-//   * A phase is  {LDS reads + ONE half-tile of LDS-DMA}  barrier  {16 MFMAs}  barrier.  The wave group wm = 1 runs one
+//   * A phase is  {LDS reads + ONE unit of LDS-DMA}  barrier  {16 MFMAs}  barrier.  The wave group wm = 1 runs one
 //     barrier behind wm = 0, so on every SIMD one wave is in its MFMA segment while its partner is in its load segment:
 //     the matrix pipe never waits for a ds_read, and the LDS-DMA stream is spread evenly (16 KiB per phase).
-//   * LDS: 2 K-tile buffers x (A [256][64] + B [256][64]), the image of form 3.  The STAGING unit is not a contiguous
-//     half but the 128 rows one quadrant reads: Aq = rows {wm*128 + q*64 ..+63}, Bq = rows {wn*64 + q*32 ..+31} over all
-//     waves (16 KiB = 16 pieces, two per wave).  A unit is read in exactly ONE phase (p0: Aq0 + Bq0, p1: Bq1, p2: Aq1;
-//     the fragments then stay in registers, 96 VGPRs), so it is free again two phases later: unit X of K-tile t+2 is
-//     issued 2-3 phases after unit X of K-tile t was read, and FOUR phases (two quadrants' worth of both groups'
-//     MFMAs) before the counted wait that precedes its first read -- s_waitcnt vmcnt(8) in p3 (Aq0, Bq0 of t+1), p0
-//     (Bq1 of t) and p1 (Aq1 of t): four units = 64 KiB always in flight, issued 16 KiB per phase.
-//   * write-after-read: restaged >= 2 phases after the only read.  read-after-write: the counted wait sits before a
-//     phase's first barrier, the read is in the next phase (one barrier more than the wait, because the two groups
-//     are a barrier apart).
-//   * Tile ends.  The K-tile body exists twice: a tile's FIRST K-tile is a copy whose counted waits let the previous
-//     epilogue's stores pass (compile-time vmcnt(8 + stores)); the steady-state copy carries no end-of-tile, bias or
-//     credit test at all.  Group 1 runs its epilogue before the tile's last barrier and group 0 after it, so the two
-//     overlap; the epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
-//   The fp32 sums are taken in the same order as in the other forms: results are bit-identical to them.
+//   * LDS: 2 K-tile buffers x (A [256][64] + B [256][64]).  The STAGING unit is the 128 rows one quadrant reads:
+//     Aq = rows {wm*128 + q*64 ..+63}, Bq = rows {wn*64 + q*32 ..+31} over all waves (16 KiB = 16 pieces, two per wave).
+//     A unit is read in exactly ONE phase (p0: Aq0 + Bq0, p1: Bq1, p2: Aq1; the fragments then stay in registers).
+//   * Schedule of K-tile t:  p0 reads Aq0, Bq0 (t), stages Aq1 (t+1);  p1 reads Bq1, stages Aq0 (t+2);  p2 reads Aq1, stages
+//     Bq0 (t+2);  p3 stages Bq1 (t+2) and holds the K-tile's ONE counted wait, s_waitcnt vmcnt(6): every unit of K-tile t+1
+//     has landed, Aq0 / Bq0 / Bq1 of t+2 stay in flight (3..7 units = 48..112 KiB in flight over a K-tile).
+//   * write-after-read: a B unit is restaged two phases after its only read; an A unit ONE phase after it -- its rows are
+//     staged and read by the SAME wave group (rA[] below: wave >> 2 = wm), whose waves have all passed the barrier that ends
+//     the reading phase's MFMA segment before any of them issues the next load segment.  read-after-write: the wait sits
+//     before p3's first barrier, the reads start in the next phase (one barrier more than the wait, because the two groups
+//     are a barrier apart).  The previous tile's epilogue stores are older than the first K-tile's Aq1 and drain with it.
+//   * Two K-tiles per loop iteration when a tile has an even number of them (every tower shape): the LDS buffer of a K-tile
+//     is then a compile-time constant -- fewer instructions in every load segment, which is the critical path of a slot.
+//   * Tile ends.  Group 1 runs its epilogue before the tile's last barrier and group 0 after it, so the two overlap; the
+//     epilogue reads the lane's bias vectors once (gemm_tile_epilogue<.., BIAS_REGS>).
+//   The fp32 sums are taken in the same order as in form 1 and in the round-2/3 form 4 (three counted waits per K-tile, units
+//   a phase later: git show 1744251:multimodal-detection-consistency_amd/csrc/gemm.hip): results are bit-identical; same-box
+//   A/B against form 4: +2.5-3.3 % on the four tower shapes, 1 355 against 1 250 TFLOP/s at 4096^3
+//   (profiles/r04_gemm_form5_ab.log).
 // ---------------------------------------------------------------------------
-// TVC_RING_F5: 0 = form 4 (three counted waits per K-tile), 1 = form 5 (units one phase earlier, ONE counted wait per
-// K-tile), 2 = form 5 with two K-tiles per loop iteration (LDS buffer parity compile-time) -- the default since round 4:
-// bit-identical to form 4, +2.5-3.3 % on the four tower shapes and 1 355 against 1 250 TFLOP/s at 4096^3 in same-box A/B
-// (scripts/gemm_f5_ab.sh, gpurun_out/r04_f5_ab.log).
-#ifndef TVC_RING_F5
-#define TVC_RING_F5 2
-#endif
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -342,91 +340,40 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     }
 #define RING4_BARRIER() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
-#define RING4_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#if TVC_RING_F5
-    // ---- form 5 (experiment): every unit is issued ONE phase earlier (Aq0 of K-tile t+2 right after the
-    // phase that read Aq0 of K-tile t -- A rows are staged and read by the SAME wave group, so one phase is a safe
-    // write-after-read distance for them; the B units keep two) and there is ONE counted wait per K-tile, in p3:
-    // vmcnt(6) retires all four units of K-tile t+1 and leaves Aq0 / Bq0 / Bq1 of K-tile t+2 in flight (3..7 units in
-    // flight over a K-tile instead of 4..5) -- the wait placement of the guide's 256^2 8-phase template.
+    // ---- prologue: K-tile 0 whole, Aq0 / Bq0 / Bq1 of K-tile 1; K-tile 0 landed and published
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
     issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{});
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     RING4_BARRIER()
-    if (wm == 1) RING4_BARRIER()
-#else
-    // ---- prologue: K-tile 0 whole, Aq0 / Bq0 of K-tile 1; Aq0 / Bq0 of K-tile 0 landed and published
-    issue_unit(U_A0{}); issue_unit(U_B0{}); issue_unit(U_B1{}); issue_unit(U_A1{});
-    issue_unit(U_A0{}); issue_unit(U_B0{});
-    RING4_WAIT8()
-    RING4_BARRIER()
     if (wm == 1) RING4_BARRIER()            // group 1 runs one barrier behind group 0 from here on
-#endif
 
-    // One K-tile.  CREDIT: the number of store instructions the previous tile's epilogue left behind the ring's loads in
-    // this wave's (in-order) vector memory queue: the three counted waits of a tile's first K-tile let them pass
-    // (vmcnt(8 + CREDIT)) instead of draining them; by the next K-tile's first wait (>= 4 phases later) they are the
-    // oldest entries.  It is compile-time: the steady-state body carries neither a compare nor a branch for it, nor for
-    // the tile's bias slice (staged ahead of the previous tile's stores, see below).
-    auto ktile = [&](int t, auto credit_c) __attribute__((always_inline)) {
-        constexpr int CREDIT = decltype(credit_c)::value;
-#define RING4_WAITC() { if (CREDIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-                        else if (CREDIT == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); \
-                        else asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
-#if TVC_RING_F5
-        // p0: read Aq0, Bq0 (t); stage Aq1 (t+1).  p1: read Bq1; stage Aq0 (t+2).  p2: read Aq1; stage Bq0 (t+2).
-        // p3: stage Bq1 (t+2); ONE wait: all of K-tile t+1 landed (the epilogue's stores of a tile's first K-tile are older
-        // than its Aq1 and drain with it: no store credit in this form).
+    // One K-tile; t selects the LDS buffer (t & 1), a literal in the two-K-tile loop below.
+    auto ktile = [&](int t) __attribute__((always_inline)) {
+        // ===== p0: read Aq0, Bq0 of K-tile t; stage Aq1 of K-tile t+1
         issue_unit(U_A1{});
         load_B(t, 0, B0f);
         load_A(t, 0, A0f);
         RING4_BARRIER()
         RING4_MFMA(A0f, B0f, 0, 0)
         RING4_BARRIER()
+        // ===== p1: read Bq1; stage Aq0 of K-tile t+2
         issue_unit(U_A0{});
         load_B(t, 1, B1f);
         RING4_BARRIER()
         RING4_MFMA(A0f, B1f, 0, 1)
         RING4_BARRIER()
+        // ===== p2: read Aq1; stage Bq0 of K-tile t+2
         issue_unit(U_B0{});
         load_A(t, 1, A1f);
         RING4_BARRIER()
         RING4_MFMA(A1f, B1f, 1, 1)
         RING4_BARRIER()
+        // ===== p3: stage Bq1 of K-tile t+2; the ONE wait: all of K-tile t+1 landed
         issue_unit(U_B1{});
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         RING4_BARRIER()
         RING4_MFMA(A1f, B0f, 1, 0)
-        return;
-#endif
-        // ===== p0: read Aq0, Bq0 of K-tile t; stage Bq1 of K-tile t+1; Bq1 of K-tile t must have landed (read in p1)
-        issue_unit(U_B1{});
-        load_B(t, 0, B0f);
-        load_A(t, 0, A0f);
-        RING4_WAITC()
-        RING4_BARRIER()
-        RING4_MFMA(A0f, B0f, 0, 0)
-        RING4_BARRIER()
-        // ===== p1: read Bq1; stage Aq1 of K-tile t+1; Aq1 of K-tile t must have landed (read in p2)
-        issue_unit(U_A1{});
-        load_B(t, 1, B1f);
-        RING4_WAITC()
-        RING4_BARRIER()
-        RING4_MFMA(A0f, B1f, 0, 1)
-        RING4_BARRIER()
-        // ===== p2: read Aq1; stage Aq0 of K-tile t+2
-        issue_unit(U_A0{});
-        load_A(t, 1, A1f);
-        RING4_BARRIER()
-        RING4_MFMA(A1f, B1f, 1, 1)
-        RING4_BARRIER()
-        // ===== p3: stage Bq0 of K-tile t+2; Aq0, Bq0 of K-tile t+1 must have landed (read in the next p0)
-        issue_unit(U_B0{});
-        RING4_WAITC()
-        RING4_BARRIER()
-        RING4_MFMA(A1f, B0f, 1, 0)
         // (the phase's second barrier is the caller's: at a tile end the two groups place their epilogues differently)
-#undef RING4_WAITC
     };
     auto stage_bias = [&](int tile) __attribute__((always_inline)) {
         if (wave == 0 && e.bias) {
@@ -436,41 +383,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         }
     };
     stage_bias(0);
-    using C0 = std::integral_constant<int, 0>;
-    // stores of a fast epilogue per wave: 16 (16-byte bf16 pieces) or 32 (fp32, or bf16 rows not 16-byte aligned)
-    constexpr int EPI_STORES = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) ? 16 : 32;
-    using CE = std::integral_constant<int, EPI_STORES>;
-    const bool credit_ok = (EPI_STORES == 32) ? ((e.ldo & 3) == 0) : ((e.ldo & 7) == 0);
-    bool credit = false;
     int t = 0;
 #pragma unroll 1
     for (ct = 0; ct < my_tiles; ++ct) {
-#if TVC_RING_F5 == 2
-        // two K-tiles per loop iteration: the LDS buffer of a K-tile is a compile-time constant (nkt even, so a tile starts on
-        // buffer 0); odd nkt takes the one-K-tile loop below
         if ((nkt & 1) == 0) {
-            ktile(0, C0{}); RING4_BARRIER() ktile(1, C0{});
+            // two K-tiles per loop iteration: a tile starts on LDS buffer 0
+            ktile(0); RING4_BARRIER() ktile(1);
 #pragma unroll 1
             for (int k = 2; k < nkt; k += 2) {
                 RING4_BARRIER()
-                ktile(0, C0{});
+                ktile(0);
                 RING4_BARRIER()
-                ktile(1, C0{});
+                ktile(1);
             }
             t += nkt;
-        } else
-#endif
-        {
-        if (credit) ktile(t, CE{}); else ktile(t, C0{});
-        ++t;
+        } else {                        // odd K-tile counts (e.g. nine planes of K = 320): one K-tile per iteration
+            ktile(t);
+            ++t;
 #pragma unroll 1
-        for (int k = 1; k < nkt; ++k, ++t) {
-            RING4_BARRIER()
-            ktile(t, C0{});
+            for (int k = 1; k < nkt; ++k, ++t) {
+                RING4_BARRIER()
+                ktile(t);
+            }
         }
-        }
-        // the NEXT tile's bias slice goes into the queue ahead of this tile's stores: with it there, wave 0's credited
-        // waits ask for one OLDER load more, never for a store
+        // the NEXT tile's bias slice goes into the queue ahead of this tile's stores
         if (ct + 1 < my_tiles) stage_bias(ct + 1);
         int i0, j0;
         tile_origin(ct, i0, j0);
@@ -486,13 +422,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         RING4_BARRIER()
         if (wm == 0) { tile_end(); }
         gemm_zero_acc(acc);
-        credit = credit_ok && (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stream's overrun stages must have landed before the LDS is given back
     if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
 #undef RING4_MFMA
 #undef RING4_BARRIER
-#undef RING4_WAIT8
 }
 
 

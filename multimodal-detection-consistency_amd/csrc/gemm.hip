@@ -225,34 +225,58 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
 //   A/B against form 4: +2.5-3.3 % on the four tower shapes, 1 355 against 1 250 TFLOP/s at 4096^3
 //   (profiles/r04_gemm_form5_ab.log).
 // ---------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
+//   SPLIT (the latent-diffusion model's fixed K split, tvc_sd.cpp Run::fixed_split): the stream walks VIRTUAL tiles
+//   (tile, slice s of S) -- K-tiles [s * nkt, (s + 1) * nkt) of the tile, nkt = K-tiles / S -- and a virtual tile ends in a
+//   store of its fp32 accumulators to ws[tile * S + s] in lane order (what gemm_splitk_partial_kernel writes, bit for bit:
+//   the same products in the same order), summed by gemm_splitk_finish_kernel.  A slice of a few-tile launch then runs at
+//   the ring's rate instead of the one-tile kernel's (about half of it).
+template <int EPI, bool SPLIT>
+__device__ __forceinline__ void gemm_ring4_body(const GemmOperands& g, const GemmEpilogue& e, int nIt, int nJt, int S, float* ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int kpp = g.ksteps_per_plane;
-    const int nkt = g.planes * kpp;
+    const int nkt = SPLIT ? g.planes * kpp / S : g.planes * kpp;
 
     RingSchedule sch;
-    sch.init(nIt * nJt);
+    sch.init(SPLIT ? nIt * nJt * S : nIt * nJt);
     const int my_tiles = sch.count();
     const int T = my_tiles * nkt;                                  // K-tiles in this workgroup's stream
     if (T == 0) return;
 
     const uint32_t smem_lds = lds_addr(smem);
-    struct Cursor { int tile, p, kk; const char* abase; const char* bbase; const char* ap; const char* bp; };
+    struct Cursor { int tile, p, kk; const char* abase; const char* bbase; const char* ap; const char* bp; int left; };
     auto opaque_lane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto cur_tile = [&](Cursor& c, int lin) __attribute__((always_inline)) {
+        int slice = 0;
+        if (SPLIT) { const int vt = lin; lin = vt / S; slice = vt - lin * S; }
         const int jt = lin / nIt;
         const int i0 = (lin - jt * nIt) * GEMM_BM, j0 = jt * GEMM_BN;
         c.abase = (const char*)(g.A + (int64_t)i0 * g.lda);
         c.bbase = (const char*)(g.B + (int64_t)j0 * g.ldb);
-        c.ap = c.abase + (int64_t)g.a_plane_off[0] * 2;
-        c.bp = c.bbase + (int64_t)g.b_plane_off[0] * 2;
+        if (SPLIT) {                        // stand on K-tile slice * nkt of the tile
+            const int b = slice * nkt;
+            c.p = b / kpp; c.kk = b - c.p * kpp; c.left = nkt;
+            c.ap = c.abase + ((int64_t)g.a_plane_off[c.p] + (int64_t)c.kk * GEMM_BK) * 2;
+            c.bp = c.bbase + ((int64_t)g.b_plane_off[c.p] + (int64_t)c.kk * GEMM_BK) * 2;
+        } else {
+            c.ap = c.abase + (int64_t)g.a_plane_off[0] * 2;
+            c.bp = c.bbase + (int64_t)g.b_plane_off[0] * 2;
+        }
     };
     auto cur_advance = [&](Cursor& c) __attribute__((always_inline)) {
         c.ap += GEMM_BK * 2; c.bp += GEMM_BK * 2;
+        if (SPLIT) {
+            if (--c.left == 0) {
+                cur_tile(c, sch.tile(++c.tile < my_tiles ? c.tile : my_tiles - 1));
+            } else if (++c.kk == kpp) {
+                c.kk = 0; ++c.p;
+                c.ap = c.abase + (int64_t)g.a_plane_off[c.p] * 2;
+                c.bp = c.bbase + (int64_t)g.b_plane_off[c.p] * 2;
+            }
+            return;
+        }
         if (++c.kk == kpp) {
             c.kk = 0;
             if (++c.p == g.planes) {
@@ -266,7 +290,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
             }
         }
     };
-    Cursor is{0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    Cursor is{0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
     cur_tile(is, sch.tile(0));
     // Staging.  Units in stream order per K-tile: Aq0, Bq0, Bq1, Aq1 (issued at phases p2, p3 of K-tile t-2 and p0, p1
     // of K-tile t-1).  The kind a phase issues is a compile-time constant; the cursor `is` stands on the K-tile being
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     int ct = 0;
 
     auto tile_origin = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
-        const int lin = sch.tile(t);
+        const int lin = SPLIT ? sch.tile(t) / S : sch.tile(t);
         const int jt = lin / nIt;
         i0 = (lin - jt * nIt) * GEMM_BM; j0 = jt * GEMM_BN;
     };
@@ -376,6 +400,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         // (the phase's second barrier is the caller's: at a tile end the two groups place their epilogues differently)
     };
     auto stage_bias = [&](int tile) __attribute__((always_inline)) {
+        if (SPLIT) return;                  // bias and epilogue belong to gemm_splitk_finish_kernel
         if (wave == 0 && e.bias) {
             int i0, j0;
             tile_origin(tile, i0, j0);
@@ -414,6 +439,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
         // that barrier a slot earlier, so the two epilogues run side by side (one slot of bias / convert / store latency
         // per tile instead of two in a row).
         auto tile_end = [&]() __attribute__((always_inline)) {
+            if (SPLIT) {
+                f32x4_t* o = (f32x4_t*)(ws + (int64_t)sch.tile(ct) * (GEMM_BM * GEMM_BN)) + threadIdx.x;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) o[(m * 4 + n) * GEMM_THREADS] = acc[m][n];
+                return;
+            }
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             gemm_tile_epilogue<EPI, true, 4, true>(acc, g, e, i0, j0, wm, wn, lane_e, smem + R3_LDS_BYTES + (ct & 1) * 1024);
@@ -427,6 +460,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g
     if (wm == 0) RING4_BARRIER()            // pairs with group 1's last barrier
 #undef RING4_MFMA
 #undef RING4_BARRIER
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_kernel(GemmOperands g, GemmEpilogue e, int nIt, int nJt) {
+    gemm_ring4_body<EPI, false>(g, e, nIt, nJt, 1, nullptr);
+}
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_ring4_split_kernel(GemmOperands g, float* ws, int nIt, int nJt, int S) {
+    GemmEpilogue e;
+    e.bias = nullptr; e.out = nullptr; e.ldo = 0;
+    gemm_ring4_body<TVC_EPI_F32, true>(g, e, nIt, nJt, S, ws);
 }
 
 
@@ -504,6 +547,7 @@ static hipError_t set_lds_attr_impl() {
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_F32>)
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_BF16>)
     SET_ATTR(gemm_ring4_kernel<TVC_EPI_GELU_BF16>)
+    SET_ATTR(gemm_ring4_split_kernel)
 #undef SET_ATTR
     return st;
 }
@@ -538,7 +582,16 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
         int S = L.splitk_fixed;
         if (S > nk64_all) S = nk64_all;
         if (!L.splitk_ws || (size_t)ntiles * S * GEMM_BM * GEMM_BN * 4 > L.splitk_ws_bytes) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(ntiles * S), block, GEMM_LDS_BYTES, stream, g, L.splitk_ws, nIt, 0, S);
+        // slices of equal depth on whole-row operands run in the ring kernel (virtual tiles); anything else in the one-tile loop
+        static const bool ring_split = [] { const char* v = getenv("TVC_GEMM_RING_SPLIT"); return !v || atoi(v) != 0; }();
+        const int vt = ntiles * S;
+        if (ring_split && nk64_all % S == 0 && nk64_all / S >= 4 && (L.I % GEMM_BM == 0 || L.a_rows_padded) &&
+            (L.J % GEMM_BN == 0 || L.b_rows_padded) && L.lda % 64 == 0 && L.ldb % 64 == 0) {
+            const dim3 rgrid(vt >= 256 ? 256 : (vt + 7) / 8 * 8);
+            hipLaunchKernelGGL(gemm_ring4_split_kernel, rgrid, block, R3_LDS_BYTES + 4096, stream, g, L.splitk_ws, nIt, nJt, S);
+        } else {
+            hipLaunchKernelGGL(gemm_splitk_partial_kernel, dim3(vt), block, GEMM_LDS_BYTES, stream, g, L.splitk_ws, nIt, 0, S);
+        }
         switch (L.epilogue) {
             case TVC_EPI_F32:
                 hipLaunchKernelGGL(gemm_splitk_finish_kernel<TVC_EPI_F32>, dim3(ntiles * 32), block, 0, stream, g, e, L.splitk_ws, nIt, 0, S);

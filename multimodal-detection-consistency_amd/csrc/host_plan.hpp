@@ -22,10 +22,11 @@ inline void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride
     // aim at 8 per chunk list (cap 128) and at most ~2048 per query (select pool 6144)
     const int keff = k > BANK_KEFF ? k : BANK_KEFF;
     int64_t ns = (int64_t)keff * R / (8 * s);
-    // small query batches (the skinny filter, M <= 64): the select pass re-scores every survivor of a query in ONE workgroup
-    // (~2 us per 16 rows), so ~2 000 survivors cost 0.3-0.5 ms there -- more than streaming a 1 M-row bank; a 8 x larger
-    // sample (its GEMM is a few tens of microseconds at these M) leaves ~250
-    const int64_t ns2 = (int64_t)keff * R / (M <= 64 ? 256 : 2048);
+    // the select pass re-scores every survivor of a query in ONE workgroup (~2 us per 16 rows): ~2 000 survivors cost 0.3-0.5 ms
+    // there whatever M is -- more than streaming a 1 M-row bank -- while the sample's GEMM is a few tens of microseconds up to
+    // M ~ 1 000 and stays under the select's saving beyond: aim at ~256 survivors per query (round 4; measured at R = 1 M,
+    // k = 10: M = 128 / 256 / 1 024 / 4 608: 1.21 / 1.12 / 2.73 / 8.89 -> 0.57 / 0.62 / 1.73 / 8.62 ms; R = 10 M: the cap below binds)
+    const int64_t ns2 = (int64_t)keff * R / 256;
     if (ns < ns2) ns = ns2;
     if (ns < 4096) ns = 4096;
     // cap: the pre-pass similarities [M, ns] fp32 stay under 8 GiB (ns = 262144 at M = 5120 keeps a

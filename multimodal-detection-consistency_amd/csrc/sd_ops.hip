@@ -135,38 +135,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
     }
 }
 
-// stats[n][group] = {mean, rstd}: one wave per (image, group), the slabs' partials summed in fp64
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nslab,
-                                                          int groups, double count, float eps, int total) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);    // (img, group)
-    const int lane = threadIdx.x & 63;
-    if (i >= total) return;
-    const int img = i / groups, g = i - img * groups;
-    double s = 0.0, q = 0.0;
-    for (int sl = lane; sl < nslab; sl += 64) {
-        const float* p = part + (((int64_t)img * nslab + sl) * groups + g) * 2;
-        s += p[0]; q += p[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (lane == 0) {
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[i * 2] = (float)mean;
-        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-}
-
 // y = ((x + tadd) - mean) * rstd * gamma + beta, optional SiLU.  One workgroup per OUTPUT row y of one image (with
 // out_pad the two border rows and the border columns are written as zeros: a convolution reads them as padding); thread
 // (pixel lane, 8-channel vector) keeps its vector's scale / shift -- rstd * gamma and beta + (tadd - mean) * rstd * gamma
 // -- in registers and walks the row's pixels: one fma (+ SiLU) per element, no integer division in the loop.
+// The image's {mean, rstd} per group come first: every workgroup sums the slabs' partials of ITS image in fp64 (thread = (group,
+// one of 8 slab lanes), then the 8 lanes in a fixed order) -- a few KB out of L2 per workgroup instead of a third kernel
+// between the statistics pass and this one.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ tadd,
-                                                       int64_t ld_t, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int64_t ld_t, const float* __restrict__ part, int nslab, double count,
+                                                       float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        uint16_t* __restrict__ y, int n, int H, int W, int C, int groups, int silu,
                                                        int in_pad, int out_pad) {
+    __shared__ double gn_sum[8][32][2];
+    __shared__ float stats[32 * 2];
     const int cv = C >> 3, cpg = C / groups;
     const int Ho = out_pad ? H + 2 : H, Wo = out_pad ? W + 2 : W;
     const int img = blockIdx.x / Ho, yo = blockIdx.x - img * Ho;
@@ -174,20 +156,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     const int Wv = cv < 256 ? cv : 256;
     const int lanes = 256 / Wv;
     const int tl = threadIdx.x / Wv, v0 = threadIdx.x - tl * Wv;
-    if (tl >= lanes) return;
     uint16_t* yrow = y + ((int64_t)img * Ho + yo) * Wo * C;
-    if (yy < 0 || yy >= H) {                     // a border row of the padded layout
+    if (yy < 0 || yy >= H) {                     // a border row of the padded layout (the whole workgroup leaves here)
+        if (tl >= lanes) return;
         for (int v = v0; v < cv; v += Wv)
             for (int xo = tl; xo < Wo; xo += lanes) *(u32x4_t*)(yrow + (int64_t)xo * C + v * 8) = u32x4_t{0u, 0u, 0u, 0u};
         return;
     }
+    {
+        const int g = threadIdx.x & 31, sl0 = threadIdx.x >> 5;
+        double s = 0.0, q = 0.0;
+        if (g < groups)
+            for (int sl = sl0; sl < nslab; sl += 8) {
+                const float* p = part + (((int64_t)img * nslab + sl) * groups + g) * 2;
+                s += p[0]; q += p[1];
+            }
+        gn_sum[sl0][g][0] = s; gn_sum[sl0][g][1] = q;
+        __syncthreads();
+        if (threadIdx.x < groups) {
+            s = 0.0; q = 0.0;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { s += gn_sum[l][threadIdx.x][0]; q += gn_sum[l][threadIdx.x][1]; }
+            const double mean = s / count;
+            double var = q / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stats[threadIdx.x * 2] = (float)mean;
+            stats[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    if (tl >= lanes) return;
     const uint16_t* xrow = x + tok_row(img, yy * W, H, W, in_pad) * C;       // pixel (yy, 0); a row's pixels are consecutive rows
     for (int v = v0; v < cv; v += Wv) {
         float sc[8], sh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = v * 8 + i, g = c / cpg;
-            const float mean = stats[(img * groups + g) * 2], rstd = stats[(img * groups + g) * 2 + 1];
+            const float mean = stats[g * 2], rstd = stats[g * 2 + 1];
             sc[i] = rstd * gamma[c];
             sh[i] = beta[c] + ((tadd ? tadd[(int64_t)img * ld_t + c] : 0.f) - mean) * sc[i];
         }
@@ -561,14 +566,11 @@ hipError_t sd_groupnorm(const uint16_t* x, const float* tadd, int64_t ld_t, cons
     const int HW = H * W, slab = gn_slab_tokens(HW);
     const int nslab = (HW + slab - 1) / slab;
     float* part = ws;
-    float* stats = ws + (size_t)n * nslab * groups * 2;
     const int cv = C >> 3, Wv = cv < 256 ? cv : 256, lanes = 256 / Wv;
     const size_t lds = (size_t)lanes * C * 2 * 4;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(n * nslab), dim3(256), lds, st, x, tadd, ld_t, part, H, W, C, groups, slab, nslab, in_pad);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 3) / 4), dim3(256), 0, st, part, stats, nslab, groups,
-                       (double)HW * (C / groups), eps, n * groups);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(n * (out_pad ? H + 2 : H)), dim3(256), 0, st, x, tadd, ld_t, stats, gamma, beta, y, n,
-                       H, W, C, groups, silu, in_pad, out_pad);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(n * (out_pad ? H + 2 : H)), dim3(256), 0, st, x, tadd, ld_t, part, nslab,
+                       (double)HW * (C / groups), eps, gamma, beta, y, n, H, W, C, groups, silu, in_pad, out_pad);
     return hipGetLastError();
 }
 

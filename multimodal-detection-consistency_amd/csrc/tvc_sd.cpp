@@ -55,6 +55,25 @@ struct Run {
     size_t off = 0, high = 0;
     size_t cap = 0;           // bytes behind `base` (the real pass): an allocation beyond it is an error, never a wild pointer
     int rc = TVC_OK;
+    // Step-invariant tensors of a sampling loop (the bf16 text states and every cross-attention's key / value projection
+    // of them: functions of the prompt only) live in their OWN bump region, walked in the same order by every evaluation:
+    // keep = 1 computes them (the loop's first evaluation), keep = 2 finds them there; keep = 0 (a lone evaluation): arena.
+    int keep = 0;
+    char* keep_base = nullptr;
+    size_t keep_off = 0, keep_high = 0, keep_cap = 0;
+    void* alloc_keep(size_t bytes) {
+        if (!keep) return alloc(bytes);
+        keep_off = (keep_off + 255) & ~(size_t)255;
+        void* p = keep_base ? keep_base + keep_off : nullptr;
+        keep_off += bytes;
+        if (keep_off > keep_high) keep_high = keep_off;
+        if (keep_base && keep_off > keep_cap) {
+            if (rc == TVC_OK) rc = fail(h, TVC_E_STATE, "tvc_sd: step-invariant region overrun");
+            return nullptr;
+        }
+        return p;
+    }
+    bool keep_fill() const { return keep != 2; }      // these tensors are computed in this evaluation
     // K split of a GEMM, chosen from the PER-SAMPLE shape only (never from the launch size): every sample's arithmetic is
     // then the same whatever batch it is generated in, so an image is bit-for-bit independent of its batch mates and of the
     // chunking of tvc_sd_generate (the reference's seed policy, src/sd_ref.py:389-412, promises reproducible references).
@@ -74,6 +93,9 @@ struct Run {
         // (the 16 x 16 level's linear layers: 120 tiles x 20 K-tiles) loses to 120 ring workgroups (measured 418 against
         // ~550 TFLOP/s); it pays from three ways on, or on a deep K (>= 32 K-tiles per slice)
         if (S == 2 && nk64 / 2 < 32) S = 1;
+        // slices of equal depth (S divides the K-tile count) run in the ring kernel (gemm.hip, gemm_ring4_split_kernel)
+        while (S > 2 && nk64 % S != 0) --S;
+        if (S == 2 && (nk64 % 2 != 0 || nk64 / 2 < 32)) S = 1;
         return S >= 2 ? (int)S : 1;
     }
     // launch with the fixed split; the fp32 partial tiles are scratch of the arena
@@ -106,9 +128,10 @@ struct Run {
         return p;
     }
     // GEMM operands get readable rows up to the next multiple of 256 (+ one tile): gemm.hip's ring form stages whole tiles
+    static int64_t pad_rows_of(int64_t r) { return (r + 255) / 256 * 256 + 256; }
     Act act(int n, int H, int W, int C) {
         Act a; a.n = n; a.H = H; a.W = W; a.C = C;
-        const int64_t rows = (a.tok() + 255) / 256 * 256 + 256;
+        const int64_t rows = pad_rows_of(a.tok());
         a.p = (uint16_t*)alloc((size_t)rows * C * 2);
         return a;
     }
@@ -308,7 +331,10 @@ struct Run {
         {   // cross-attention onto the text states
             Act q = linear(n2, t + "attn2.to_q.weight", "", C);
             Act cx; cx.n = n; cx.H = 1; cx.W = S->d.ctx; cx.C = S->d.cross_attention_dim; cx.p = const_cast<uint16_t*>(ctx16);
-            Act kv = linear(cx, t + "attn2.to_kv.weight", "", 2 * C);
+            Act kv = cx; kv.C = 2 * C;                       // step-invariant (alloc_keep)
+            kv.p = (uint16_t*)alloc_keep((size_t)pad_rows_of(cx.tok()) * 2 * C * 2);
+            if (keep_fill()) gemm(W(t + "attn2.to_kv.weight"), 2 * C, cx.C, cx.p, cx.tok(), nullptr, kv.p, 2 * C, TVC_EPI_BF16, S->d.ctx);
+            else (void)W(t + "attn2.to_kv.weight");
             Act a = act(n, x.H, x.W, C);
             attention(q.p, C, kv.p, 2 * C, kv.p + C, 2 * C, a.p, C, n, heads, T, S->d.ctx, dh);
             Act o = linear(a, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", C);
@@ -375,8 +401,8 @@ void unet_forward(Run& R, const float* latents, int n, int H, int W, float times
     const tvc_sd_desc& d = S->d;
     const int nb = d.n_blocks, c0 = d.block_out_channels[0], Tdim = 4 * c0;
     // text states -> bf16 rows
-    uint16_t* ctx16 = (uint16_t*)R.alloc((size_t)pad_rows((int64_t)n * d.ctx) * d.cross_attention_dim * 2);
-    if (R.live()) R.hip(sd_cast_silu(ctx, ctx16, (int64_t)n * d.ctx * d.cross_attention_dim, 0, R.st), "ctx cast");
+    uint16_t* ctx16 = (uint16_t*)R.alloc_keep((size_t)pad_rows((int64_t)n * d.ctx) * d.cross_attention_dim * 2);
+    if (R.live() && R.keep_fill()) R.hip(sd_cast_silu(ctx, ctx16, (int64_t)n * d.ctx * d.cross_attention_dim, 0, R.st), "ctx cast");
     // time embedding MLP, then every resnet's time projection in one GEMM: tadd fp32 [n, temb_total]
     uint16_t* te = (uint16_t*)R.alloc((size_t)pad_rows(n) * c0 * 2);
     float* t1 = (float*)R.alloc((size_t)n * Tdim * 4);
@@ -682,11 +708,28 @@ static int sd_generate_chunk(tvc_handle* h, const float* cond_dev, const float* 
     auto acp = [&](int t) { return t >= 0 ? S->alphas_cumprod[t < T ? t : T - 1] : S->alphas_cumprod[0]; };
     int counter = 0, n_ets = 0, head = 0;            // ets ring: slot (head - 1 - k) mod 4 = k-th newest
     auto slot = [&](int k) { return ets + (size_t)((head - 1 - k + 8) % 4) * ne; };
+    // the step-invariant tensors (bf16 text states, every cross-attention's K / V of them) are computed by the first
+    // evaluation and kept for the others: 16 projections per evaluation less, bit-identical
+    size_t keep_bytes = 0;
+    {
+        Run dry{h, S, st, true};
+        dry.keep = 1;
+        unet_forward(dry, nullptr, 2 * n, H, W, 0.f, nullptr, nullptr);
+        if (dry.rc != TVC_OK) return dry.rc;
+        keep_bytes = dry.keep_high + 4096;
+    }
+    if ((rc = ensure(h, WS_SD3, keep_bytes))) return rc;
+    bool first = true;
     for (int t : order) {
         HIP_TRY(hipMemcpyAsync(lat2, latents_dev, ne * 4, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(lat2 + ne, latents_dev, ne * 4, hipMemcpyDeviceToDevice, st));
-        rc = with_arena(h, st, WS_SD0, [&](Run& R) { unet_forward(R, lat2, 2 * n, H, W, (float)t, ctx2, eps2); });
+        rc = with_arena(h, st, WS_SD0, [&](Run& R) {
+            R.keep = first ? 1 : 2;
+            if (!R.dry) { R.keep_base = (char*)h->ws[WS_SD3].p; R.keep_cap = h->ws[WS_SD3].n; }
+            unet_forward(R, lat2, 2 * n, H, W, (float)t, ctx2, eps2);
+        });
         if (rc) return rc;
+        first = false;
         // classifier-free guidance, then PNDMScheduler.step_plms
         int prev_t = t - ratio, tt = t;
         float* e_new = tmp;

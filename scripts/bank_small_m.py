@@ -11,7 +11,7 @@ for R in Rs:
     eng = pkg.TVCEngine()
     bank = pkg.synth.make_bank(R, D, seed=7, device="cuda:0", dtype=torch.bfloat16)
     eng.set_bank(bank)
-    for M in (1, 10, 48, 256, 1024):
+    for M in [int(m) for m in os.environ.get("BANK_MS", "1,10,48,256,1024").split(",")]:
         g = torch.Generator(device="cuda:0").manual_seed(M)
         q = torch.randn((M, D), generator=g, device="cuda:0"); q = q / q.norm(dim=-1, keepdim=True)
         for _ in range(3): eng.bank_search(q, k, 0.1, want_moments=False)

@@ -12,11 +12,13 @@ sd.generate_batch(prompts, list(range(n)), steps, 7.5, 512, 512)
 torch.cuda.synchronize()
 eng.profile_begin()
 t0 = time.perf_counter()
-sd.generate_batch(prompts, list(range(n)), steps, 7.5, 512, 512)
+imgs = sd.generate_batch(prompts, list(range(n)), steps, 7.5, 512, 512)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 prof = eng.profile_end()
-print(json.dumps({"steps": steps, "images": n, "seconds": round(dt, 4),
+import hashlib
+md5 = hashlib.md5(torch.as_tensor(imgs).float().cpu().numpy().tobytes()).hexdigest()
+print(json.dumps({"steps": steps, "images": n, "seconds": round(dt, 4), "images_md5": md5,
                   "ms": {c: round(v["ms"], 2) for c, v in prof.items()},
                   "gemm_tflops": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1),
                   "attn_tflops": round(prof["attention"]["work"] / (prof["attention"]["ms"] * 1e-3) / 1e12, 1)}), flush=True)

@@ -23,10 +23,10 @@ inline void bank_plan(int64_t R, int M, int k, int* n_sample, int* sample_stride
     const int keff = k > BANK_KEFF ? k : BANK_KEFF;
     int64_t ns = (int64_t)keff * R / (8 * s);
     // the select pass re-scores every survivor of a query in ONE workgroup (~2 us per 16 rows): ~2 000 survivors cost 0.3-0.5 ms
-    // there whatever M is -- more than streaming a 1 M-row bank -- while the sample's GEMM is a few tens of microseconds up to
-    // M ~ 1 000 and stays under the select's saving beyond: aim at ~256 survivors per query (round 4; measured at R = 1 M,
-    // k = 10: M = 128 / 256 / 1 024 / 4 608: 1.21 / 1.12 / 2.73 / 8.89 -> 0.57 / 0.62 / 1.73 / 8.62 ms; R = 10 M: the cap below binds)
-    const int64_t ns2 = (int64_t)keff * R / 256;
+    // there whatever M is -- more than streaming a 1 M-row bank -- while the sample's GEMM and the tau selection over it grow
+    // with M: aim at ~256 survivors per query up to M = 2 048 (round 4; measured at R = 1 M, k = 10, M = 128 / 256 / 1 024 / 2 048:
+    // 1.21 / 1.12 / 2.73 / 4.15 -> 0.57 / 0.62 / 1.73 / 3.26 ms; at M = 4 608 the two costs cancel: 6.9 -> 7.3 ms at k = 5)
+    const int64_t ns2 = (int64_t)keff * R / (M <= 2048 ? 256 : 2048);
     if (ns < ns2) ns = ns2;
     if (ns < 4096) ns = 4096;
     // cap: the pre-pass similarities [M, ns] fp32 stay under 8 GiB (ns = 262144 at M = 5120 keeps a

@@ -194,10 +194,14 @@ const char* tvc_last_error(tvc_handle* h);
  * TVC_OPT_SD_ARENA_BYTES (default 48 GiB): budget of the activation arena of ONE UNet evaluation inside tvc_sd_generate.
  * The arena grows linearly with the samples of an evaluation (about 0.75 GB per image at 64 x 64 latents: both halves of
  * classifier-free guidance); a batch that would exceed the budget is generated in chunks of whole sampling loops -- every
- * image is independent of its batch mates, so chunking changes no pixel -- instead of failing with TVC_E_NOMEM. */
+ * image is independent of its batch mates, so chunking changes no pixel -- instead of failing with TVC_E_NOMEM.
+ * TVC_OPT_SD_STREAMS (default 2; 1 = off): inside tvc_sd_generate the unconditional and the conditional half of a UNet
+ * evaluation run on two HIP streams (the caller's and one the handle owns, forked / joined by events), each in its own
+ * half of the arena: a launch of one half fills the compute units the other half's partial tile round leaves idle.  Every
+ * sample's arithmetic is independent of its batch mates, so the images are bit-identical with 1 and 2. */
 enum { TVC_OPT_TEXT_PACKING = 1, TVC_OPT_MAX_CHUNK_IMAGES = 2, TVC_OPT_MAX_CHUNK_TEXTS = 3,
        TVC_OPT_BANK_FILTER = 4, TVC_OPT_TEXT_GROUP = 5, TVC_OPT_POOLED_LAST_LAYER = 6, TVC_OPT_TOWER_PRECISION = 7,
-       TVC_OPT_SD_ARENA_BYTES = 8 };
+       TVC_OPT_SD_ARENA_BYTES = 8, TVC_OPT_SD_STREAMS = 9 };
 int tvc_set_option(tvc_handle* h, int32_t option, int64_t value);
 
 /* Register fp32 copies of the tower weights for TVC_OPT_TOWER_PRECISION = 1 (either may be NULL).  Referenced, not

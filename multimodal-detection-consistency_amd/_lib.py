@@ -24,6 +24,7 @@ TVC_OPT_TEXT_GROUP = 5
 TVC_OPT_POOLED_LAST_LAYER = 6
 TVC_OPT_TOWER_PRECISION = 7
 TVC_OPT_SD_ARENA_BYTES = 8
+TVC_OPT_SD_STREAMS = 9
 
 
 class TVCError(RuntimeError):

@@ -46,37 +46,34 @@ struct Cand {
 
 // (bank_plan: host_plan.hpp)
 
-// tau[q] = (k-th largest of 256 group maxima of s0[q, :]) minus a safety margin
+// tau[q] = (k-th largest of 256 group maxima of the query's sample similarities) minus a safety margin
 // FILTER form: tau is lowered by the bound of what the one-product pass leaves out,
 //   |b.q - bhi.qhi| <= |bhi||qlo| + |blo||qhi| + |blo||qlo|   (bank_bounds = max |bhi|, max |blo|)
-__global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict__ s0, int n_sample,
-                                                        int k, float* __restrict__ tau,
-                                                        const uint16_t* __restrict__ qplanes, int D,
-                                                        const float* __restrict__ bank_bounds) {
-    __shared__ float gm[256];
-    __shared__ float nrm[2][4];
-    const int q = blockIdx.x, t = threadIdx.x;
+// Shared tail of the two tau kernels: thread t < 256 brings group t's maximum `m`; needs blockDim.x >= 256.
+__device__ __forceinline__ void kth_finish(float m, int q, int k, float* __restrict__ tau, const uint16_t* __restrict__ qplanes,
+                                           int D, const float* __restrict__ bank_bounds, float* gm, float (*nrm)[4]) {
+    const int t = threadIdx.x;
     float margin = 0.f;
     if (qplanes) {
         float h2 = 0.f, l2 = 0.f;
-        const uint16_t* qr = qplanes + (int64_t)q * 2 * D;
-        for (int c = t; c < D; c += 256) {
-            const float h = bf16_bits_to_f32(qr[c]), l = bf16_bits_to_f32(qr[D + c]);
-            h2 = fmaf(h, h, h2); l2 = fmaf(l, l, l2);
+        if (t < 256) {
+            const uint16_t* qr = qplanes + (int64_t)q * 2 * D;
+            for (int c = t; c < D; c += 256) {
+                const float h = bf16_bits_to_f32(qr[c]), l = bf16_bits_to_f32(qr[D + c]);
+                h2 = fmaf(h, h, h2); l2 = fmaf(l, l, l2);
+            }
+            h2 = wave_sum(h2); l2 = wave_sum(l2);
+            if ((t & 63) == 0) { nrm[0][t >> 6] = h2; nrm[1][t >> 6] = l2; }
         }
-        h2 = wave_sum(h2); l2 = wave_sum(l2);
-        if ((t & 63) == 0) { nrm[0][t >> 6] = h2; nrm[1][t >> 6] = l2; }
         __syncthreads();
         const float qh = sqrtf(nrm[0][0] + nrm[0][1] + nrm[0][2] + nrm[0][3]);
         const float ql = sqrtf(nrm[1][0] + nrm[1][1] + nrm[1][2] + nrm[1][3]);
         const float bh = bank_bounds[0], bl = bank_bounds[1];
         margin = (bh * ql + bl * qh + bl * ql) * 1.001f + 4e-6f * (1.f + bh * qh);
     }
-    const float* row = s0 + (int64_t)q * n_sample;
-    float m = -INFINITY;
-    for (int i = t; i < n_sample; i += 256) m = fmaxf(m, row[i]);
-    gm[t] = m;
+    if (t < 256) gm[t] = m;
     __syncthreads();
+    if (t >= 256) return;
     int rank = 0;
     for (int u = 0; u < 256; ++u) {
         const float o = gm[u];
@@ -91,6 +88,52 @@ __global__ __launch_bounds__(256) void kth_bound_kernel(const float* __restrict_
         if (!(v == v)) v = -INFINITY;
         tau[q] = v;
     }
+}
+
+// s0 [M, n_sample] (the dense sample GEMM's output) -> tau.  1 024 threads scan the row with 16-byte loads, four in flight
+// per thread (one workgroup of 256 threads with scalar loads took 44-51 us per launch whatever M was: 245 dependent
+// round trips); thread t's elements belong to group t & 255 -- any partition into 256 disjoint groups gives a valid bound.
+__global__ __launch_bounds__(1024) void kth_bound_kernel(const float* __restrict__ s0, int n_sample,
+                                                         int k, float* __restrict__ tau,
+                                                         const uint16_t* __restrict__ qplanes, int D,
+                                                         const float* __restrict__ bank_bounds) {
+    __shared__ float gm[256];
+    __shared__ float part[3][256];
+    __shared__ float nrm[2][4];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const float* row = s0 + (int64_t)q * n_sample;
+    float m = -INFINITY;
+    if ((n_sample & 3) == 0) {
+        const f32x4_t* row4 = (const f32x4_t*)row;
+        const int n4 = n_sample >> 2;
+        int i = t;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const f32x4_t a = row4[i], b = row4[i + 1024], c = row4[i + 2048], d = row4[i + 3072];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]))));
+        }
+        for (; i < n4; i += 1024) {
+            const f32x4_t a = row4[i];
+            m = fmaxf(m, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+        }
+    } else {
+        for (int i = t; i < n_sample; i += 1024) m = fmaxf(m, row[i]);
+    }
+    if (t >= 256) part[(t >> 8) - 1][t & 255] = m;
+    __syncthreads();
+    if (t < 256) m = fmaxf(fmaxf(m, part[0][t]), fmaxf(part[1][t], part[2][t]));
+    kth_finish(m, q, k, tau, qplanes, D, bank_bounds, gm, nrm);
+}
+
+// gmax [M, 256] (bank_sample_skinny_kernel's group maxima) -> tau; also clears the search's overflow flag
+__global__ __launch_bounds__(256) void kth_groups_kernel(const float* __restrict__ gmax, int k, float* __restrict__ tau,
+                                                         const uint16_t* __restrict__ qplanes, int D,
+                                                         const float* __restrict__ bank_bounds, int32_t* __restrict__ overflow) {
+    __shared__ float gm[256];
+    __shared__ float nrm[2][4];
+    const int q = blockIdx.x;
+    if (q == 0 && threadIdx.x == 0) *overflow = 0;
+    kth_finish(gmax[(int64_t)q * 256 + threadIdx.x], q, k, tau, qplanes, D, bank_bounds, gm, nrm);
 }
 
 // max over rows of |hi plane| and |lo plane| (squared, as ordered uint bit patterns)
@@ -548,68 +591,263 @@ static hipError_t launch_bank_filter_skinny(const uint16_t* bank, int64_t ldb, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pass 0 for small query batches over a bf16 bank (M <= 64): the sample's 256 group maxima straight from the matrix
+// pipe -- no [M, n_sample] similarities, no scan of them.  (The dense sample GEMM ran one 256 x 256 tile per workgroup
+// for M query columns, 49 us, and kth_bound_kernel another 46 us: a third of a 1 M-row search's time that is not the
+// bank stream.)  Workgroup (G, qb): sample rows [G * per, (G + 1) * per) -- bank rows i * sample_stride -- against
+// the 16 * NQT queries of block qb, whose [hi | lo] planes sit in LDS (pitch 4 D + 16 bytes, conflict-free as in the
+// filter kernel); both products of a bf16 bank, b.qhi + b.qlo, go into one accumulator (exact bf16 x bf16 products,
+// fp32 sums: the value the dense sample GEMM computed, in another k order -- inside kth_finish's slack).
+// Lane (r16, g) owns query n * 16 + r16 and the group's rows 4 g .. 4 g + 3: a running maximum per lane, reduced over
+// g by two shuffles and over the eight waves through LDS.  Rows past the group's end are clamped for the load and
+// masked to -inf (a duplicated row in two groups would break "k distinct sample rows are >= tau").
+// ---------------------------------------------------------------------------------------------------------------
+template <int KB, int NQT>
+__global__ __launch_bounds__(512) void bank_sample_skinny_kernel(const uint16_t* __restrict__ bank, int64_t ldb,
+                                                                  const uint16_t* __restrict__ qplanes, int M, int n_sample,
+                                                                  int sample_stride, int per, float* __restrict__ gmax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = KB * 64;
+    constexpr int QPITCH = 4 * D + 16;
+    float* red = (float*)(smem + NQT * 16 * QPITCH);          // [8][NQT * 16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = blockIdx.x, q0 = blockIdx.y * NQT * 16;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int i_lo = G * per;
+    int i_hi = i_lo + per;
+    if (i_hi > n_sample) i_hi = n_sample;
+    const int n_groups = i_hi > i_lo ? (i_hi - i_lo + 15) >> 4 : 0;
+    const char* qbase = smem + r16 * QPITCH + g * 32;
+    float mx[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) mx[n] = -INFINITY;
+
+    auto load_group = [&](int grp, u32x4_t (&a)[2 * KB]) {
+        int i = i_lo + grp * 16 + r16;
+        if (i >= i_hi) i = i_hi - 1;
+        const uint16_t* src = bank + (int64_t)i * sample_stride * ldb + g * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            a[2 * kb] = *(const u32x4_t*)(src + kb * 64);
+            a[2 * kb + 1] = *(const u32x4_t*)(src + kb * 64 + 8);
+        }
+    };
+    auto compute_group = [&](int grp, const u32x4_t (&a)[2 * KB]) {
+        f32x4_t acc[NQT];
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, a[2 * kb + hf]);
+#pragma unroll
+                for (int n = 0; n < NQT; ++n) {
+                    const char* qp = qbase + n * 16 * QPITCH + kb * 128 + hf * 16;
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *(const bf16x8_t*)qp, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *(const bf16x8_t*)(qp + 2 * D), acc[n], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keeps hipcc from hoisting every fragment read of the group (154 spills)
+        }
+        const int i0 = i_lo + grp * 16 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NQT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i0 + r < i_hi) mx[n] = fmaxf(mx[n], acc[n][r]);
+    };
+    // two register sets: a wave has two or three groups (n_sample / 256 rows per workgroup), both requested up front -- and
+    // before the queries' planes are copied to LDS (NQT * 16 * D / 4 sixteen-byte pieces, 3 per thread and query at D = 768,
+    // unrolled so that a thread's pieces are in flight together): the launch is latency-bound, the two latencies overlap
+    u32x4_t a0[2 * KB], a1[2 * KB];
+    int grp = wave;
+    if (grp < n_groups) load_group(grp, a0);
+    {
+        constexpr int PIECES = NQT * 16 * (D / 4);
+        constexpr int ROUNDS = (PIECES + 511) / 512;
+#pragma unroll 6
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int idx = tid + u * 512;
+            const int q = idx / (D / 4), c = idx - q * (D / 4);
+            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+            if (idx < PIECES && q0 + q < M) v = *(const u32x4_t*)(qplanes + (int64_t)(q0 + q) * 2 * D + c * 8);
+            if (idx < PIECES) *(u32x4_t*)(smem + q * QPITCH + c * 16) = v;
+        }
+    }
+    __syncthreads();
+    while (grp < n_groups) {
+        if (grp + 8 < n_groups) load_group(grp + 8, a1);
+        compute_group(grp, a0);
+        grp += 8;
+        if (grp >= n_groups) break;
+        if (grp + 8 < n_groups) load_group(grp + 8, a0);
+        compute_group(grp, a1);
+        grp += 8;
+    }
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) {
+        float v = mx[n];
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        if (g == 0) red[wave * (NQT * 16) + n * 16 + r16] = v;
+    }
+    __syncthreads();
+    if (tid < NQT * 16 && q0 + tid < M) {
+        float v = red[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v = fmaxf(v, red[w * (NQT * 16) + tid]);
+        gmax[(int64_t)(q0 + tid) * 256 + G] = v;
+    }
+}
+
+// 16 * NQT queries per workgroup, NQT <= 3: both planes of 48 queries are 146 KB of LDS at D = 768 (64 queries: two blocks of 32)
+template <int KB>
+static hipError_t launch_sample_skinny_kb(const uint16_t* bank, int64_t ldb, const uint16_t* qplanes, int M, int n_sample,
+                                          int sample_stride, float* gmax, hipStream_t stream) {
+    const int nqt = M <= 16 ? 1 : (M > 32 && M <= 48) ? 3 : 2;
+    const int per = (n_sample + 255) / 256;
+    const dim3 grid(256, (M + nqt * 16 - 1) / (nqt * 16));
+    const size_t lds = (size_t)nqt * 16 * (KB * 256 + 16) + 8 * nqt * 16 * 4;
+    static std::once_flag once;
+    static hipError_t ast = hipSuccess;
+    std::call_once(once, [] {
+        ast = hipFuncSetAttribute((const void*)bank_sample_skinny_kernel<KB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  16 * (KB * 256 + 16) + 8 * 16 * 4);
+        if (ast == hipSuccess)
+            ast = hipFuncSetAttribute((const void*)bank_sample_skinny_kernel<KB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      32 * (KB * 256 + 16) + 8 * 32 * 4);
+        if (ast == hipSuccess)
+            ast = hipFuncSetAttribute((const void*)bank_sample_skinny_kernel<KB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      48 * (KB * 256 + 16) + 8 * 48 * 4);
+    });
+    if (ast != hipSuccess) return ast;
+#define SAMPLE_CASE(N)                                                                                                          \
+    case N:                                                                                                                     \
+        hipLaunchKernelGGL((bank_sample_skinny_kernel<KB, N>), grid, dim3(512), lds, stream, bank, ldb, qplanes, M, n_sample,   \
+                           sample_stride, per, gmax);                                                                           \
+        break;
+    switch (nqt) {
+        SAMPLE_CASE(1)
+        SAMPLE_CASE(2)
+        SAMPLE_CASE(3)
+    }
+#undef SAMPLE_CASE
+    return hipGetLastError();
+}
+static hipError_t launch_bank_sample_skinny(const uint16_t* bank, int64_t ldb, int D, const uint16_t* qplanes, int M, int n_sample,
+                                            int sample_stride, float* gmax, hipStream_t stream) {
+    switch (D) {
+        case 128: return launch_sample_skinny_kb<2>(bank, ldb, qplanes, M, n_sample, sample_stride, gmax, stream);
+        case 512: return launch_sample_skinny_kb<8>(bank, ldb, qplanes, M, n_sample, sample_stride, gmax, stream);
+        case 768: return launch_sample_skinny_kb<12>(bank, ldb, qplanes, M, n_sample, sample_stride, gmax, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // (v desc, idx asc) ordering
 __device__ __forceinline__ bool cand_better(float v, int idx, float ov, int oidx) {
     return (v > ov) || (v == ov && idx < oidx);
 }
 
-__global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict__ cand,
-                                                          const int32_t* __restrict__ cand_cnt,
-                                                          const float* __restrict__ mom_part, int S, int M,
-                                                          int k, int32_t* __restrict__ topk_idx,
-                                                          float* __restrict__ topk_sim,
-                                                          float* __restrict__ moments,
-                                                          int32_t* __restrict__ overflow,
-                                                          const uint16_t* __restrict__ rs_bank, int64_t rs_ld,
-                                                          int rs_planes, int D,
-                                                          const float* __restrict__ rs_rows,
-                                                          int64_t idx_offset) {
+// One workgroup of SEL_T threads per query.  Round 4: 1 024 threads (16 waves x 4 rows in flight in the re-scoring: the
+// ~250-350 listed rows of a query took 16-22 round trips of ~2 us with 4 waves, a fifth of a small search), and the list
+// gather reads a thread's chunk counts in one batch of independent loads instead of one dependent load per chunk.
+#define SEL_T 1024
+#define SEL_W (SEL_T / 64)
+#define SEL_CPT 8          // chunks per thread kept in registers (S <= SEL_T * SEL_CPT; more: the counts are read twice)
+__global__ __launch_bounds__(SEL_T) void bank_select_kernel(const Cand* __restrict__ cand,
+                                                            const int32_t* __restrict__ cand_cnt,
+                                                            const float* __restrict__ mom_part, int S, int M,
+                                                            int k, int32_t* __restrict__ topk_idx,
+                                                            float* __restrict__ topk_sim,
+                                                            float* __restrict__ moments,
+                                                            int32_t* __restrict__ overflow,
+                                                            const uint16_t* __restrict__ rs_bank, int64_t rs_ld,
+                                                            int rs_planes, int D,
+                                                            const float* __restrict__ rs_rows,
+                                                            int64_t idx_offset) {
     __shared__ Cand pool[BANK_POOL];
     __shared__ __attribute__((aligned(16))) float qs[BANK_MAX_RESCORE_D];
-    __shared__ int scan[256];
-    __shared__ float red_v[4];
-    __shared__ int red_i[4];
-    __shared__ int red_p[4];
-    __shared__ float mom_red[4][4];
+    __shared__ int wsum[SEL_W];
+    __shared__ float red_v[2][SEL_W];
+    __shared__ int red_i[2][SEL_W];
+    __shared__ int red_p[2][SEL_W];
+    __shared__ float mom_red[SEL_W][4];
     const int q = blockIdx.x, t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
 
-    // chunks handled by this thread: c = t, t+256, ...
+    // chunks handled by this thread: c = t, t + SEL_T, ...
+    const bool few = S <= SEL_T * SEL_CPT;
+    int cnt[SEL_CPT];
     int mine = 0;
-    for (int c = t; c < S; c += 256) mine += cand_cnt[(int64_t)c * M + q];
-    scan[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = (t >= o) ? scan[t - o] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
+    if (few) {
+#pragma unroll
+        for (int u = 0; u < SEL_CPT; ++u) {
+            const int c = t + u * SEL_T;
+            cnt[u] = c < S ? cand_cnt[(int64_t)c * M + q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_CPT; ++u) mine += cnt[u];
+    } else {
+        for (int c = t; c < S; c += SEL_T) mine += cand_cnt[(int64_t)c * M + q];
     }
-    const int total_all = scan[255];
-    int off = scan[t] - mine;
-    for (int c = t; c < S; c += 256) {
-        const int n = cand_cnt[(int64_t)c * M + q];
-        const Cand* src = cand + ((int64_t)c * M + q) * BANK_CAP;
-        for (int i = 0; i < n; ++i) {
-            if (off < BANK_POOL) pool[off] = src[i];
-            ++off;
+    // exclusive prefix of `mine` over the workgroup: wave scan + the waves' totals
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total_all = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_W; ++w) {
+        const int v = wsum[w];
+        if (w < wave) wbase += v;
+        total_all += v;
+    }
+    int off = wbase + incl - mine;
+    if (few) {
+#pragma unroll
+        for (int u = 0; u < SEL_CPT; ++u) {
+            const int n = cnt[u];
+            if (n > 0) {
+                const Cand* src = cand + ((int64_t)(t + u * SEL_T) * M + q) * BANK_CAP;
+                for (int i = 0; i < n; ++i) {
+                    if (off < BANK_POOL) pool[off] = src[i];
+                    ++off;
+                }
+            }
+        }
+    } else {
+        for (int c = t; c < S; c += SEL_T) {
+            const int n = cand_cnt[(int64_t)c * M + q];
+            const Cand* src = cand + ((int64_t)c * M + q) * BANK_CAP;
+            for (int i = 0; i < n; ++i) {
+                if (off < BANK_POOL) pool[off] = src[i];
+                ++off;
+            }
         }
     }
     if (t == 0 && total_all > BANK_POOL) atomicOr(overflow, 2);
     const int total = total_all < BANK_POOL ? total_all : BANK_POOL;
     if (rs_bank) {
-        for (int c = t; c < D; c += 256) qs[c] = rs_rows[(int64_t)q * D + c];
+        for (int c = t; c < D; c += SEL_T) qs[c] = rs_rows[(int64_t)q * D + c];
     }
     __syncthreads();
 
     if (rs_bank) {
-        // exact fp32 re-scoring of the listed rows: one wave per row, four rows in flight
-        for (int i0 = wave; i0 < total; i0 += 16) {
+        // exact fp32 re-scoring of the listed rows: one wave per row, four rows in flight per wave
+        for (int i0 = wave; i0 < total; i0 += 4 * SEL_W) {
             float part[4];
             const uint16_t* br[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int i = i0 + u * 4;
+                int i = i0 + u * SEL_W;
                 i = i < total ? i : total - 1;
                 br[u] = rs_bank + ((int64_t)pool[i].idx - idx_offset) * rs_ld;
                 part[u] = 0.f;
@@ -640,17 +878,20 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v = wave_sum(part[u]);
-                const int i = i0 + u * 4;
+                const int i = i0 + u * SEL_W;
                 if (lane == 0 && i < total) pool[i].v = v;
             }
         }
         __syncthreads();
     }
 
+    // k rounds of arg-max, ONE barrier each: the waves' bests go to a slot pair indexed by the round's parity, every wave
+    // reduces the SEL_W entries again by shuffles (same result in every wave), and the winner is struck out by the thread
+    // that owns its pool slot (slot % SEL_T: the only thread that ever reads it again)
     for (int r = 0; r < k; ++r) {
         float bv = -INFINITY;
         int bi = 0x7fffffff, bp = -1;
-        for (int i = t; i < total; i += 256) {
+        for (int i = t; i < total; i += SEL_T) {
             const Cand c = pool[i];
             if (c.idx >= 0 && cand_better(c.v, c.idx, bv, bi)) { bv = c.v; bi = c.idx; bp = i; }
         }
@@ -661,29 +902,28 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
             const int op = __shfl_xor(bp, o, 64);
             if (op >= 0 && (bp < 0 || cand_better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
         }
-        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; red_p[wave] = bp; }
+        const int par = r & 1;
+        if (lane == 0) { red_v[par][wave] = bv; red_i[par][wave] = bi; red_p[par][wave] = bp; }
         __syncthreads();
-        if (t == 0) {
-            float fv = red_v[0]; int fi = red_i[0], fp = red_p[0];
-            for (int w = 1; w < 4; ++w)
-                if (red_p[w] >= 0 && (fp < 0 || cand_better(red_v[w], red_i[w], fv, fi))) {
-                    fv = red_v[w]; fi = red_i[w]; fp = red_p[w];
-                }
-            if (fp >= 0) {
-                topk_idx[(int64_t)q * k + r] = fi;
-                topk_sim[(int64_t)q * k + r] = fv;
-                pool[fp].idx = -1;     // taken
-            } else {
-                topk_idx[(int64_t)q * k + r] = -1;
-                topk_sim[(int64_t)q * k + r] = -INFINITY;
-            }
+        float fv = red_v[par][lane & (SEL_W - 1)];
+        int fi = red_i[par][lane & (SEL_W - 1)], fp = red_p[par][lane & (SEL_W - 1)];
+#pragma unroll
+        for (int o = SEL_W / 2; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(fv, o, 64);
+            const int oi = __shfl_xor(fi, o, 64);
+            const int op = __shfl_xor(fp, o, 64);
+            if (op >= 0 && (fp < 0 || cand_better(ov, oi, fv, fi))) { fv = ov; fi = oi; fp = op; }
         }
-        __syncthreads();
+        if (t == 0) {
+            topk_idx[(int64_t)q * k + r] = fp >= 0 ? fi : -1;
+            topk_sim[(int64_t)q * k + r] = fp >= 0 ? fv : -INFINITY;
+        }
+        if (fp >= 0 && (fp & (SEL_T - 1)) == t) pool[fp].idx = -1;     // taken
     }
 
     if (moments) {
         float s = 0.f, s2 = 0.f, m = -INFINITY, c = 0.f;
-        for (int ch = t; ch < S; ch += 256) {
+        for (int ch = t; ch < S; ch += SEL_T) {
             const float* p = mom_part + ((int64_t)ch * M + q) * 4;
             s += p[0]; s2 += p[1]; m = fmaxf(m, p[2]); c += p[3];
         }
@@ -692,10 +932,9 @@ __global__ __launch_bounds__(256) void bank_select_kernel(const Cand* __restrict
         __syncthreads();
         if (t == 0) {
             float* o = moments + (int64_t)q * 4;
-            o[0] = mom_red[0][0] + mom_red[1][0] + mom_red[2][0] + mom_red[3][0];
-            o[1] = mom_red[0][1] + mom_red[1][1] + mom_red[2][1] + mom_red[3][1];
-            o[2] = fmaxf(fmaxf(mom_red[0][2], mom_red[1][2]), fmaxf(mom_red[2][2], mom_red[3][2]));
-            o[3] = mom_red[0][3] + mom_red[1][3] + mom_red[2][3] + mom_red[3][3];
+            float s0 = 0.f, s1 = 0.f, m2 = -INFINITY, s3 = 0.f;
+            for (int w = 0; w < SEL_W; ++w) { s0 += mom_red[w][0]; s1 += mom_red[w][1]; m2 = fmaxf(m2, mom_red[w][2]); s3 += mom_red[w][3]; }
+            o[0] = s0; o[1] = s1; o[2] = m2; o[3] = s3;
         }
     }
 }
@@ -812,20 +1051,37 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     // fast form: one-product filter + exact re-scoring (needs no per-row moments)
     const bool filter = (L.moments == nullptr) && L.bank_bounds && L.rows && D <= BANK_MAX_RESCORE_D && L.allow_filter;
 
+    // small query batches: the bank streamed once from HBM against <= 64 query columns (TVC_BANK_SKINNY=0: off, for A/B runs)
+    static const bool skinny_on = [] { const char* v = getenv("TVC_BANK_SKINNY"); return !v || atoi(v) != 0; }();
+    const bool skinny = filter && skinny_on && skinny_covers(D, L.M) && L.ldb % 8 == 0;
+    // ... and, over a bf16 bank, the sample's group maxima by the same route (TVC_BANK_SKINNY_SAMPLE=0: the dense sample GEMM)
+    static const bool skinny_sample_on = [] { const char* v = getenv("TVC_BANK_SKINNY_SAMPLE"); return !v || atoi(v) != 0; }();
+
     // ---- pass 0: sample GEMM + tau ----------------------------------------
-    GemmLaunch G;
-    G.A = L.bank; G.lda = L.ldb * (int64_t)L.sample_stride; G.I = L.n_sample;
-    G.B = L.qplanes; G.ldb = 2 * (int64_t)D; G.J = L.M; G.K = D; G.planes = planes;
-    for (int p = 0; p < 4; ++p) { G.a_plane_off[p] = a_off[p]; G.b_plane_off[p] = b_off[p]; }
-    G.out = L.s0; G.ldo = L.n_sample; G.epilogue = TVC_EPI_F32;
-    hipError_t st = launch_gemm_bf16(G, stream);
-    if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(kth_bound_kernel, dim3(L.M), dim3(256), 0, stream, L.s0, L.n_sample, L.k, L.tau,
-                       filter ? L.qplanes : nullptr, D, L.bank_bounds);
-    st = hipGetLastError();
-    if (st != hipSuccess) return st;
-    st = hipMemsetAsync(L.overflow, 0, sizeof(int32_t), stream);
-    if (st != hipSuccess) return st;
+    hipError_t st;
+    if (skinny && skinny_sample_on && L.bank_planes == 1) {
+        // s0 holds >= M * n_sample floats, n_sample >= 256 or the whole bank: the first [M, 256] of it take the group maxima
+        st = launch_bank_sample_skinny(L.bank, L.ldb, D, L.qplanes, L.M, L.n_sample, L.sample_stride, L.gmax, stream);
+        if (st != hipSuccess) return st;
+        hipLaunchKernelGGL(kth_groups_kernel, dim3(L.M), dim3(256), 0, stream, L.gmax, L.k, L.tau, L.qplanes, D, L.bank_bounds,
+                           L.overflow);
+        st = hipGetLastError();
+        if (st != hipSuccess) return st;
+    } else {
+        GemmLaunch G;
+        G.A = L.bank; G.lda = L.ldb * (int64_t)L.sample_stride; G.I = L.n_sample;
+        G.B = L.qplanes; G.ldb = 2 * (int64_t)D; G.J = L.M; G.K = D; G.planes = planes;
+        for (int p = 0; p < 4; ++p) { G.a_plane_off[p] = a_off[p]; G.b_plane_off[p] = b_off[p]; }
+        G.out = L.s0; G.ldo = L.n_sample; G.epilogue = TVC_EPI_F32;
+        st = launch_gemm_bf16(G, stream);
+        if (st != hipSuccess) return st;
+        hipLaunchKernelGGL(kth_bound_kernel, dim3(L.M), dim3(1024), 0, stream, L.s0, L.n_sample, L.k, L.tau,
+                           filter ? L.qplanes : nullptr, D, L.bank_bounds);
+        st = hipGetLastError();
+        if (st != hipSuccess) return st;
+        st = hipMemsetAsync(L.overflow, 0, sizeof(int32_t), stream);
+        if (st != hipSuccess) return st;
+    }
 
     // ---- pass 1: fused GEMM + filter ---------------------------------------
     GemmOperands g;
@@ -843,9 +1099,7 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     // the one-tile-at-a-time loop, for A/B runs); the ragged last bank tile is handled inside the kernel
     static const bool ring_on = [] { const char* v = getenv("TVC_BANK_RING"); return !v || atoi(v) != 0; }();
     const bool ring = filter && ring_on && L.q_rows_padded && (g.lda % 64 == 0) && (g.ldb % 64 == 0) && L.R >= GEMM_BM;
-    // small query batches: the bank streamed once from HBM against <= 64 query columns (TVC_BANK_SKINNY=0: off, for A/B runs)
-    static const bool skinny_on = [] { const char* v = getenv("TVC_BANK_SKINNY"); return !v || atoi(v) != 0; }();
-    if (filter && skinny_on && skinny_covers(D, L.M) && L.ldb % 8 == 0) {
+    if (skinny) {
         st = launch_bank_filter_skinny(L.bank, L.ldb, D, L.qplanes, e, L.S, tpc * GEMM_BM, stream);
         if (st != hipSuccess) return st;
     } else if (ring)
@@ -861,7 +1115,7 @@ hipError_t launch_bank_search(const BankSearchLaunch& L, hipStream_t stream) {
     if (st != hipSuccess) return st;
 
     // ---- pass 2: select -----------------------------------------------------
-    hipLaunchKernelGGL(bank_select_kernel, dim3(L.M), dim3(256), 0, stream, (const Cand*)L.cand,
+    hipLaunchKernelGGL(bank_select_kernel, dim3(L.M), dim3(SEL_T), 0, stream, (const Cand*)L.cand,
                        L.cand_cnt, L.mom_part, L.S, L.M, L.k, L.topk_idx, L.topk_sim, L.moments, L.overflow,
                        filter ? L.bank : nullptr, L.ldb, L.bank_planes, D, L.rows, L.idx_offset);
     return hipGetLastError();

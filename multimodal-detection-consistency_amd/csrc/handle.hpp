@@ -99,6 +99,10 @@ struct tvc_handle {
     bool split_ready = false;
     struct SdState* sd = nullptr;   // latent-diffusion model (tvc_sd.cpp), owned
     size_t sd_arena_bytes = (size_t)48 << 30;   // TVC_OPT_SD_ARENA_BYTES: activation arena of one UNet evaluation
+    // TVC_OPT_SD_STREAMS: the two classifier-free-guidance halves of a UNet evaluation on two HIP streams (tvc_sd.cpp)
+    int sd_streams = 2;
+    hipStream_t sd_aux = nullptr;
+    hipEvent_t sd_fork = nullptr, sd_join = nullptr;
 };
 void tvc_sd_free(tvc_handle* h);    // tvc_sd.cpp
 void tvc_split_free(tvc_handle* h); // tvc_split.cpp

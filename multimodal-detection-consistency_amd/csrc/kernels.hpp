@@ -95,6 +95,7 @@ struct BankSearchLaunch {
     int64_t idx_offset = 0;
     // workspace (sized by bank_workspace_bytes)
     float* s0 = nullptr;              // [M, n_sample] pre-pass similarities
+    float* gmax = nullptr;            // [M, 256] group maxima of the sample (small-M form: bank_sample_skinny_kernel)
     float* tau = nullptr;             // [M]
     void* cand = nullptr;             // [S, M, CAP] {float, int}
     int32_t* cand_cnt = nullptr;      // [S, M]

@@ -455,7 +455,7 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     bank_plan(bk.R, M, k, &L.n_sample, &L.sample_stride, &L.S, &L.cap);
     int rc;
     if ((rc = ensure(h, WS_QPLANES, (size_t)((M + 255) / 256 * 256) * 2 * D * 2))) return rc;
-    if ((rc = ensure(h, WS_S0, (size_t)M * L.n_sample * 4))) return rc;
+    if ((rc = ensure(h, WS_S0, (size_t)M * (L.n_sample > 256 ? L.n_sample : 256) * 4))) return rc;
     if ((rc = ensure(h, WS_TAU, (size_t)M * 4))) return rc;
     if ((rc = ensure(h, WS_CAND, (size_t)L.S * M * L.cap * 8))) return rc;
     if ((rc = ensure(h, WS_CAND_CNT, (size_t)L.S * M * 4))) return rc;
@@ -466,7 +466,7 @@ int tvc_bank_search(tvc_handle* h, const float* rows_dev, int32_t M, int32_t k, 
     L.qplanes = (const uint16_t*)h->ws[WS_QPLANES].p; L.q_rows_padded = true; L.M = M; L.k = k; L.count_thr = count_thr;
     L.idx_offset = idx_offset;
     L.rows = rows_dev; L.bank_bounds = bk.bounds; L.allow_filter = h->bank_filter;
-    L.s0 = (float*)h->ws[WS_S0].p; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
+    L.s0 = (float*)h->ws[WS_S0].p; L.gmax = L.s0; L.tau = (float*)h->ws[WS_TAU].p; L.cand = h->ws[WS_CAND].p;
     L.cand_cnt = (int32_t*)h->ws[WS_CAND_CNT].p; L.mom_part = (float*)h->ws[WS_MOM_PART].p;
     L.overflow = (int32_t*)h->ws[WS_OVERFLOW].p;
     L.topk_idx = topk_idx_dev; L.topk_sim = topk_sim_dev; L.moments = moments_dev;
@@ -833,6 +833,9 @@ int tvc_set_option(tvc_handle* h, int32_t option, int64_t value) {
         case TVC_OPT_SD_ARENA_BYTES:
             if (value < ((int64_t)1 << 28)) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_SD_ARENA_BYTES must be >= 256 MiB");
             h->sd_arena_bytes = (size_t)value; return TVC_OK;
+        case TVC_OPT_SD_STREAMS:
+            if (value < 1 || value > 2) return fail(h, TVC_E_INVALID, "tvc_set_option: TVC_OPT_SD_STREAMS must be 1 or 2");
+            h->sd_streams = (int)value; return TVC_OK;
         default: return fail(h, TVC_E_INVALID, "tvc_set_option: unknown option");
     }
 }

@@ -28,7 +28,11 @@ struct SdState {
 };
 
 void tvc_sd_free(tvc_handle* h) {
-    if (!h || !h->sd) return;
+    if (!h) return;
+    if (h->sd_aux) { (void)hipStreamSynchronize(h->sd_aux); (void)hipStreamDestroy(h->sd_aux); h->sd_aux = nullptr; }
+    if (h->sd_fork) { (void)hipEventDestroy(h->sd_fork); h->sd_fork = nullptr; }
+    if (h->sd_join) { (void)hipEventDestroy(h->sd_join); h->sd_join = nullptr; }
+    if (!h->sd) return;
     if (h->sd->temb_w) (void)hipFree(h->sd->temb_w);
     if (h->sd->temb_b) (void)hipFree(h->sd->temb_b);
     delete h->sd;
@@ -710,24 +714,54 @@ static int sd_generate_chunk(tvc_handle* h, const float* cond_dev, const float* 
     auto slot = [&](int k) { return ets + (size_t)((head - 1 - k + 8) % 4) * ne; };
     // the step-invariant tensors (bf16 text states, every cross-attention's K / V of them) are computed by the first
     // evaluation and kept for the others: 16 projections per evaluation less, bit-identical
-    size_t keep_bytes = 0;
-    {
-        Run dry{h, S, st, true};
-        dry.keep = 1;
-        unet_forward(dry, nullptr, 2 * n, H, W, 0.f, nullptr, nullptr);
-        if (dry.rc != TVC_OK) return dry.rc;
-        keep_bytes = dry.keep_high + 4096;
+    // Two streams (TVC_OPT_SD_STREAMS): the unconditional and the conditional half of an evaluation are independent until
+    // the guidance step, so each runs on its own stream in its own half of the arena (and of the step-invariant region).
+    // A half's launches have half the tiles -- at 12 images the 32 x 32 level's 327-tile convolutions were two tile rounds
+    // for 1.28 rounds of work --, and whatever compute units one half's partial round leaves idle take the other half's
+    // next launch.  Per-sample arithmetic does not depend on the batch (Run::fixed_split), so the images do not change.
+    const int parts = h->sd_streams >= 2 ? 2 : 1;
+    const int pn = 2 * n / parts;                     // samples per part
+    if (parts == 2 && !h->sd_aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->sd_aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->sd_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->sd_join, hipEventDisableTiming));
     }
-    if ((rc = ensure(h, WS_SD3, keep_bytes))) return rc;
+    size_t keep_part = 0, arena_part[2] = {0, 0};     // arena: [0] the loop's first evaluation (fills the kept tensors), [1] the others
+    for (int pass = 0; pass < 2; ++pass) {
+        Run dry{h, S, st, true};
+        dry.keep = pass == 0 ? 1 : 2;
+        unet_forward(dry, nullptr, pn, H, W, 0.f, nullptr, nullptr);
+        if (dry.rc != TVC_OK) return dry.rc;
+        if (pass == 0) keep_part = (dry.keep_high + 4096 + 255) & ~(size_t)255;
+        arena_part[pass] = (dry.high + 4096 + 255) & ~(size_t)255;
+    }
+    if ((rc = ensure(h, WS_SD3, keep_part * parts))) return rc;
+    if ((rc = ensure(h, WS_SD0, std::max(arena_part[0], arena_part[1]) * parts))) return rc;
     bool first = true;
     for (int t : order) {
         HIP_TRY(hipMemcpyAsync(lat2, latents_dev, ne * 4, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(lat2 + ne, latents_dev, ne * 4, hipMemcpyDeviceToDevice, st));
-        rc = with_arena(h, st, WS_SD0, [&](Run& R) {
-            R.keep = first ? 1 : 2;
-            if (!R.dry) { R.keep_base = (char*)h->ws[WS_SD3].p; R.keep_cap = h->ws[WS_SD3].n; }
-            unet_forward(R, lat2, 2 * n, H, W, (float)t, ctx2, eps2);
-        });
+        const size_t ap = arena_part[first ? 0 : 1];
+        if (parts == 2) {
+            HIP_TRY(hipEventRecord(h->sd_fork, st));
+            HIP_TRY(hipStreamWaitEvent(h->sd_aux, h->sd_fork, 0));
+        }
+        rc = TVC_OK;
+        for (int part = 0; part < parts; ++part) {
+            Run run{h, S, part == 0 ? st : h->sd_aux, false};
+            run.base = (char*)h->ws[WS_SD0].p + (size_t)part * ap;
+            run.cap = ap;
+            run.keep = first ? 1 : 2;
+            run.keep_base = (char*)h->ws[WS_SD3].p + (size_t)part * keep_part;
+            run.keep_cap = keep_part;
+            const size_t so = (size_t)part * pn;          // first sample of this part
+            unet_forward(run, lat2 + so * (ne / n), pn, H, W, (float)t, ctx2 + so * (ctx_elems / n), eps2 + so * (ne / n));
+            if (run.rc != TVC_OK && rc == TVC_OK) rc = run.rc;
+        }
+        if (parts == 2) {          // joined even after an error: the caller's stream must not run ahead of the other half
+            HIP_TRY(hipEventRecord(h->sd_join, h->sd_aux));
+            HIP_TRY(hipStreamWaitEvent(st, h->sd_join, 0));
+        }
         if (rc) return rc;
         first = false;
         // classifier-free guidance, then PNDMScheduler.step_plms

@@ -190,6 +190,10 @@ int main(int argc, char** argv) {
     OK(tvc_sd_generate(h, ctx, ctx, lat, 5, 16, 16, 4, 7.5f, img, nullptr));
     OK(tvc_set_option(h, TVC_OPT_SD_ARENA_BYTES, (int64_t)1 << 28));            // chunks of a few images
     OK(tvc_sd_generate(h, ctx, ctx, lat, 6, 16, 16, 3, 7.5f, nullptr, nullptr));
+    CHECK(tvc_set_option(h, TVC_OPT_SD_STREAMS, 3) == TVC_E_INVALID && tvc_set_option(h, TVC_OPT_SD_STREAMS, 0) == TVC_E_INVALID);
+    OK(tvc_set_option(h, TVC_OPT_SD_STREAMS, 1));                               // both guidance halves in one arena, one stream
+    OK(tvc_sd_generate(h, ctx, ctx, lat, 3, 16, 16, 3, 7.5f, nullptr, nullptr));
+    OK(tvc_set_option(h, TVC_OPT_SD_STREAMS, 2));
     CHECK(tvc_sd_generate(h, ctx, ctx, lat, 2, 11, 12, 3, 7.5f, nullptr, nullptr) == TVC_E_INVALID);
     CHECK(tvc_sd_generate(h, ctx, ctx, lat, 2, 16, 16, 1, 7.5f, nullptr, nullptr) == TVC_E_INVALID);
     float* x = (float*)buf((size_t)2 * 192 * 16 * 16, 4); float* y = (float*)buf((size_t)2 * 128 * 32 * 32, 4); float* temb = (float*)buf(2 * 256, 4);

@@ -112,7 +112,7 @@ def test_bank_search_small_query_batches_skinny_form(gpu_engine, R, D, dtype):
     qall = _unit((65, D), 400 + D)
     big_i, big_s, _ = gpu_engine.bank_search(qall.cuda(), k, want_moments=False)
     gpu_engine.bank_status()
-    for M in (1, 10, 16, 17, 48, 64):
+    for M in (1, 10, 16, 17, 32, 33, 48, 64):
         q = qall[:M]
         idx, sim, _ = gpu_engine.bank_search(q.cuda(), k, want_moments=False)
         gpu_engine.bank_status()

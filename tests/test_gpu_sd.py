@@ -240,6 +240,29 @@ def test_generate_validates_sizes_and_chunks_by_the_arena_budget(pkg, sd):
     assert torch.equal(parts, one)            # an image does not depend on its batch mates (src/sd_ref.py:389-412: seed policy)
 
 
+def test_two_stream_guidance_halves_are_bit_identical(pkg, sd):
+    """TVC_OPT_SD_STREAMS = 2 (default): the unconditional and the conditional half of every UNet evaluation run on two HIP
+    streams, each in its own half of the arena; = 1: one launch sequence over both halves.  Same images, bit for bit (a
+    sample's arithmetic does not depend on its batch mates), with and without the arena chunking, latents and decoded."""
+    arch, uw, vw, k = sd
+    g = torch.Generator().manual_seed(19)
+    n = 3
+    cond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
+    uncond = torch.randn((n, arch.ctx, arch.cross_attention_dim), generator=g)
+    lat0 = torch.randn((n, 4, 16, 16), generator=g)
+    two, img2 = k.generate(cond, uncond, lat0, 4, 7.5, decode=True)
+    k.engine.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 1)
+    try:
+        one, img1 = k.generate(cond, uncond, lat0, 4, 7.5, decode=True)
+    finally:
+        k.engine.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 2)
+    assert torch.isfinite(two).all() and torch.equal(two, one) and torch.equal(img2, img1)
+    again, _ = k.generate(cond, uncond, lat0, 4, 7.5, decode=False)         # and the run repeats itself
+    assert torch.equal(again, two)
+    with pytest.raises(pkg.TVCError):
+        k.engine.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 3)
+
+
 def test_preprocess_images_matches_torch_antialias(pkg, sd):
     """``tvc_preprocess_images`` (resize + centre crop + normalise on the device) vs torch's antialiased interpolate on
     the CPU (the PIL filter semantics on float pixels): bicubic short-side + crop (CLIP preprocess) and bilinear

@@ -710,6 +710,30 @@ def main():
                                  "gemm_tflops_in_step": round(prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12, 1),
                                  "gemm_gflop_per_image_step": round(fwd_flop / 1e9, 1),
                                  "note": "forward (the backward's inputs are kept, nothing is recomputed) + the four dX GEMMs per layer; no weight gradients"}
+        # two batches of 32 in flight, each on its own stream and engine handle (what PGDAttacker.perturb does by default,
+        # PGDAttackConfig.concurrent_batches = 2): every batch computed as it is alone
+        try:
+            eng2 = pkg.TVCEngine(arch, weights[0], None, device=str(dev))
+            clean2 = images[pb:2 * pb].contiguous() if B >= 2 * pb else clean.clone()
+            adv2, mom2 = clean2.clone(), torch.zeros_like(clean2)
+            jobs = [(eng, s_img, adv, clean, mom), (eng2, s_txt, adv2, clean2, mom2)]
+
+            def pgd_iter2():          # no join between steps: each batch runs its own loop (timed() ends on a device-wide sync)
+                for e_, st_, adv_, clean_, mom_ in jobs:
+                    with torch.cuda.stream(st_):
+                        e_.encode_image_grad(adv_, True)
+                        g_ = e_.encode_image_backward(g_out)
+                        e_.pgd_step(adv_, clean_, g_, mom_, 8 / 255, 2 / 255, 0.9, 0.0, 1.0, False)
+
+            sync()
+            d2, _ = timed(pgd_iter2, ks, 2)
+            sync()
+            out["pgd_inner_loop"]["two_batches_in_flight"] = {"image_steps_per_s": round(2 * pb * ks / d2, 1), "batch": pb,
+                                                              "ms_per_step_pair": round(d2 / ks * 1e3, 2)}
+            eng2.close()
+            del adv2, mom2, clean2
+        except Exception as ex:       # an extra: never the reason a bench run fails
+            out["pgd_inner_loop"]["two_batches_in_flight"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if extras and B >= 256 and a.model == "ViT-L/14":
         # ---- the same inner loop at a full chip: batch 256 (the reference's 32 is a default of PGDAttackConfig, not a
@@ -775,11 +799,17 @@ def main():
             imgs = sd.generate_batch(prompts, seeds_sd, steps_sd, 7.5, 512, 512)
             return eng.encode_image(clip.preprocess_tensor(imgs), True)
 
+        sd_eng = sd.text_engine
         sd_step(); sync()
+        # the category times come from a pass with the two guidance halves on ONE stream (TVC_OPT_SD_STREAMS = 1): with two
+        # streams the launches of the halves overlap and an event pair around a launch also spans the other half's kernels
+        sd_eng.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 1)
+        d_sd1, _ = timed(sd_step, 1, 1)
         eng.profile_begin()
         sd_step(); sync()
         prof = eng.profile_end()
-        d_sd, _ = timed(sd_step, 2, 0)
+        sd_eng.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 2)
+        d_sd, _ = timed(sd_step, 2, 1)
         gemm_tf = prof["gemm"]["work"] / (prof["gemm"]["ms"] * 1e-3) / 1e12 if prof["gemm"]["ms"] > 0 else 0.0
         # the same generator at a batch that fills the chip's low-resolution levels (80 samples: the 8 x 8 level's 32 token
         # tiles x 5 feature tiles, the 16 x 16 level's 255): every image is bit-identical to the one the 12-image batch makes
@@ -791,10 +821,12 @@ def main():
             return eng.encode_image(clip.preprocess_tensor(imgs), True)
 
         sd_step_big(); sync()
+        sd_eng.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 1)
         eng.profile_begin()
         sd_step_big(); sync()
         prof_big = eng.profile_end()
-        d_big, _ = timed(sd_step_big, 1, 0)
+        sd_eng.set_option(pkg._lib.TVC_OPT_SD_STREAMS, 2)
+        d_big, _ = timed(sd_step_big, 1, 1)
         gemm_tf_big = prof_big["gemm"]["work"] / (prof_big["gemm"]["ms"] * 1e-3) / 1e12 if prof_big["gemm"]["ms"] > 0 else 0.0
         # ---- BASELINE configs[4] end to end: the full three-method detector (text variants + SD references + consistency,
         # src/detector.py:345-439) on 4 queries x 3 generated references each, 20 steps -- generation dominates
@@ -813,6 +845,10 @@ def main():
                                "full_defense_note": "AdversarialDetector.batch_detect with all three methods (text_variants + sd_reference + "
                                                     "consistency), 4 queries x 3 references x 20 steps per batch (BASELINE configs[4])",
                                "seconds_per_batch": round(d_sd / 2, 3),
+                               "streams": {"two_streams_images_per_s": round(n_img * 2 / d_sd, 3), "one_stream_images_per_s": round(n_img / d_sd1, 3),
+                                           "note": "TVC_OPT_SD_STREAMS: the unconditional and the conditional half of every UNet evaluation on two "
+                                                   "HIP streams (default) / on one; bit-identical images; kernel_ms_per_batch and gemm_tflops are "
+                                                   "measured in the one-stream form (unoverlapped launch durations)"},
                                "batch_of_40": {"images_per_s": round(n_big / d_big, 3), "seconds_per_batch": round(d_big, 3),
                                                "gemm_tflops": round(gemm_tf_big, 1),
                                                "gemm_frac_of_peak": round(gemm_tf_big / PEAK_BF16_DENSE_TFLOPS, 4),

@@ -54,6 +54,10 @@ class PGDAttackConfig:
     mixed_precision: bool = False
     pin_memory: bool = True
     gradient_clip_value: float = 0.0
+    # batches of `batch_size` in flight at once (not in the reference): each on its own HIP stream and its own engine handle
+    # (same weights), so that the launches of one batch fill the compute units the other's leave idle -- a batch of 32 images
+    # is 132 output tiles in half of its GEMMs, on 256 compute units.  Every batch's arithmetic is what it is alone.
+    concurrent_batches: int = 2
 
 
 class PGDAttacker:
@@ -86,6 +90,45 @@ class PGDAttacker:
             noise = (torch.rand(clean.shape, generator=self._gen) * 2 - 1) * c.epsilon
             adv = torch.clamp(adv + noise.to(clean.device), c.clip_min, c.clip_max)
         return adv.contiguous()
+
+    def _engine_pool(self, n: int):
+        """`n` engines (the model's own first) and as many side streams; the extra handles reference the same tower
+        weights (uploaded once more: 0.6 GB for ViT-L/14) and own their workspaces / kept activations."""
+        if not hasattr(self, "_pool"):
+            self._pool, self._streams = [self.engine], []
+        while len(self._pool) < n:
+            from .engine import TVCEngine
+            self._pool.append(TVCEngine(self.engine.arch, self.engine._w_host[0], None, device=str(self.device)))
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(self.device))
+        return self._pool[:n], self._streams[:n]
+
+    def _steps_concurrent(self, jobs: Sequence[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]) -> List[torch.Tensor]:
+        """`_steps` for several batches at once, batch j on stream j / engine j; the random starts are drawn in batch
+        order, so the outputs equal the sequential ones bit for bit."""
+        if len(jobs) == 1:
+            return [self._steps(*jobs[0])]
+        c = self.config
+        engines, streams = self._engine_pool(len(jobs))
+        state = []
+        for clean, text_f, target_f in jobs:
+            adv = self._random_start(clean)
+            mom = torch.zeros_like(adv) if c.use_momentum else None
+            targeted = bool(c.targeted and target_f is not None)
+            g_out = ((-target_f if targeted else text_f) / clean.shape[0]).contiguous()
+            state.append((clean, adv, mom, g_out))
+        main = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(main)
+        for _ in range(c.num_steps):
+            for (clean, adv, mom, g_out), eng, st in zip(state, engines, streams):
+                with torch.cuda.stream(st):
+                    eng.encode_image_grad(adv, True)
+                    grad = eng.encode_image_backward(g_out)
+                    eng.pgd_step(adv, clean, grad, mom, c.epsilon, c.alpha, c.momentum, c.clip_min, c.clip_max, c.targeted)
+        for st in streams:
+            main.wait_stream(st)
+        return [adv for _, adv, _, _ in state]
 
     def _steps(self, clean: torch.Tensor, text_f: torch.Tensor, target_f: Optional[torch.Tensor],
                history: Optional[Dict[str, list]] = None) -> torch.Tensor:
@@ -165,11 +208,16 @@ class PGDAttacker:
         feeds straight into ``pipeline.detect``."""
         x = self._to_batch(images)
         bs = self.config.batch_size
+        nc = max(1, int(self.config.concurrent_batches))
         outs = []
-        for i in range(0, x.shape[0], bs):
-            tf = self._text_unit(texts[i:i + bs])
-            gf = self._text_unit(target_texts[i:i + bs]) if target_texts else None
-            outs.append(self._steps(x[i:i + bs].contiguous(), tf, gf))
+        starts = list(range(0, x.shape[0], bs))
+        for g0 in range(0, len(starts), nc):
+            jobs = []
+            for i in starts[g0:g0 + nc]:
+                tf = self._text_unit(texts[i:i + bs])
+                gf = self._text_unit(target_texts[i:i + bs]) if target_texts else None
+                jobs.append((x[i:i + bs].contiguous(), tf, gf))
+            outs.extend(self._steps_concurrent(jobs))
         return torch.cat(outs)
 
     def _batch_pgd_attack(self, batch_images: torch.Tensor, batch_texts: List[str],

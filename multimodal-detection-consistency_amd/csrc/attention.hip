@@ -22,6 +22,11 @@
 // 365-400 us against 277-292 us per ViT-L/14 layer call -- its 72 staging registers leave room for 0-4 pinned K tiles instead
 // of 15 and the block loop becomes LDS-bound.
 //
+// A start stagger (round 4, second session: of the first two workgroups of a compute unit, the one in wave slot 1 sleeps
+// 6 400 / 12 800 / 19 200 / 25 600 clocks before its fill, so that one workgroup fills while the other multiplies;
+// scripts/attn_stagger_ab.sh, profiles/r04_attention_stagger_ab.log): 292-293 -> 283-286 us whatever the delay, -2.5 %:
+// the two residents' lock-step is not what separates 285 us from the ~170 us floor.  Not kept.
+//
 // What bounds it (in-kernel clock stamps, round 3): the memory system's rate on the packed rows' 128-byte
 // per-head pieces, not vector issue.  Hence the XCD-contiguous item order, the unconditional one-latency fill, the wait
 // for the next block's Q fragments placed BEFORE the block's stores (vmcnt counts stores), and the 16-byte stores.

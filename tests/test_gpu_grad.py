@@ -181,6 +181,29 @@ def test_pgd_attacker_vs_oracle_recipe(pkg):
     clip.engine.close()
 
 
+def test_pgd_concurrent_batches_are_bit_identical(pkg):
+    """PGDAttackConfig.concurrent_batches = 2 (default): two batches of `batch_size` in flight on two HIP streams / two
+    engine handles.  Every batch is computed as it is alone and the random starts are drawn in batch order, so `perturb`
+    returns the same pixels, bit for bit, as the one-batch-at-a-time loop (a ragged last batch and an odd batch count
+    included)."""
+    arch = pkg.get_arch("ViT-T/16-test")
+    vw, tw = pkg.synth.make_clip_weights(arch, seed=0)
+    Q = 44                                          # batches of 8: five full ones and a ragged one of 4
+    clean = pkg.synth.make_images(Q, arch.image_size, seed=5).cuda()
+    texts = [f"a photo of thing {i}" for i in range(Q)]
+    clip = pkg.CLIPModel(pkg.CLIPConfig(model_name=arch.name), weights=(vw, tw))
+    outs = {}
+    for nc in (1, 2, 3):
+        atk = pkg.PGDAttacker(clip, pkg.PGDAttackConfig(batch_size=8, random_seed=7, num_steps=4, concurrent_batches=nc))
+        outs[nc] = atk.perturb(clean, texts)
+        torch.cuda.synchronize()
+        for e in getattr(atk, "_pool", [])[1:]:
+            e.close()
+    assert torch.isfinite(outs[1]).all() and (outs[1] - clean.clamp(0, 1)).abs().max().item() > 1e-3
+    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[3], outs[1])
+    clip.engine.close()
+
+
 def test_pgd_attacker_vs_committed_fixture(pkg):
     """ViT-B/32, the first PGD batch of tests/golden/pgd_b32_q1000.npz (oracle/make_pgd_fixture.py: queries 500..549,
     generator seed SEED_PGD + 500): the HIP attack, started from the same noise, lands on the same side of the clean

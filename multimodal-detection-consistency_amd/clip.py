@@ -229,6 +229,26 @@ class CLIPModel:
         out = torch.cat(outs) if len(outs) != 1 else outs[0]
         return out if on_dev else out.cpu()
 
+    def encode_image_beside(self, x: torch.Tensor, normalize: bool = True):
+        """The image tower of a batch enqueued on the model's SIDE stream, so that the text tower the caller enqueues next
+        (on the current stream) runs beside it -- the two towers of a query are independent until the cosines, and for
+        one query each is a chain of ~300 latency-bound launches.  Returns ``join``: call it before the first consumer;
+        it makes the current stream wait for the side stream and returns the rows ``[B, D]``."""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fi = self.engine.encode_image(x, normalize)
+
+        def join() -> torch.Tensor:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(side)
+            fi.record_stream(cur)
+            return fi
+        return join
+
     def encode_image_tensor(self, x: torch.Tensor, requires_grad: bool = False) -> torch.Tensor:
         """Tensor in, tensor out (src/detector.py:626).  ``requires_grad=True`` (src/attacks/pgd_attack.py:254,459,480,
         src/attacks/hubness_attack.py:586): the result carries an autograd node whose backward is the HIP input-gradient

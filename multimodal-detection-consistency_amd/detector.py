@@ -153,13 +153,16 @@ class AdversarialDetector:
     def batch_detect(self, images, texts: Sequence[str], methods: Optional[List[str]] = None,
                      variants: Optional[Sequence[Sequence[str]]] = None,
                      reference_images: Optional[Sequence[Sequence[Any]]] = None,
-                     keep_features: Optional[Dict[str, torch.Tensor]] = None) -> List[Dict[str, Any]]:
+                     keep_features: Optional[Dict[str, torch.Tensor]] = None,
+                     image_rows=None) -> List[Dict[str, Any]]:
         """src/detector.py:711-734, truly batched.  ``keep_features`` (a dict) receives the device rows
         ``image`` [n, D] and ``text`` [n, D] (the ORIGINAL texts) so that a caller needing them again
         (the pipeline's retrieval step) does not encode the same texts twice.  Queries are grouped by their variant count so
         every group is one launch; ALL device work (image tower, text tower, reference-image tower,
         consistency kernels) is enqueued before the first device-to-host copy, and the host
-        tokenises while the GPU runs the image tower."""
+        tokenises while the GPU runs the image tower.  ``image_rows``: the ``join`` of a ``CLIPModel.encode_image_beside``
+        call the caller has ALREADY enqueued for these images (the pipeline starts the image tower before it generates the
+        text variants on the host); ``images`` is then not encoded again."""
         methods = methods or self.config.detection_methods
         t0 = time.time()
         clip = self._get_clip_model()
@@ -167,10 +170,14 @@ class AdversarialDetector:
         if isinstance(images, torch.Tensor) and images.dim() == 3:
             images = images.unsqueeze(0)
         n = len(texts)
-        x, _ = clip._images_to_device(images if isinstance(images, torch.Tensor) else list(images))
-        if x.shape[0] != n:
-            raise ValueError("number of images and texts differ")
-        fi = eng.encode_image(x, True)                      # enqueued first: overlaps the host work below
+        if image_rows is None:
+            x, _ = clip._images_to_device(images if isinstance(images, torch.Tensor) else list(images))
+            if x.shape[0] != n:
+                raise ValueError("number of images and texts differ")
+            join_fi = clip.encode_image_beside(x, True)     # enqueued first, on the side stream: beside the host work AND the text tower
+        else:
+            join_fi = image_rows
+        fi = None
         # a requested method is scored whenever its component exists (src/detector.py:375,382), also when
         # the component yields nothing for a query (0.0 + 'error', :457-458, :524-525)
         tv_on = "text_variants" in methods and self.config.use_text_variants
@@ -189,6 +196,8 @@ class AdversarialDetector:
                 flat.append(texts[i])
                 flat.extend(variants[i])
             ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
+            if fi is None:
+                fi = join_fi()
             sel = fi if len(ids) == n else fi[torch.as_tensor(ids, device=fi.device)].contiguous()
             pending.append((N, ids, eng.consistency(sel, ft, cfg)))
             if keep_features is not None:
@@ -201,6 +210,8 @@ class AdversarialDetector:
         # reference images, one consistency launch per distinct count (cos(image, ref_j) = record words 0, 12..).
         sd_pending, sd_counts = [], [0] * n
         sd_errors: Dict[int, str] = {}                      # query -> message: the method scores 0.0 + 'error' (:555-557)
+        if fi is None:
+            fi = join_fi()
         if sd_on:
             fr = None
             if reference_images is None and hasattr(self.sd_generator, "reference_features"):
@@ -521,7 +532,8 @@ class MultiModalDefenseDetector:
         eng = clip.engine
         n = len(texts)
         x, _ = clip._images_to_device(images)
-        fi = eng.encode_image(x, True)                      # enqueued first: overlaps the host work below
+        join_fi = clip.encode_image_beside(x, True)         # enqueued first, on the side stream: beside the host work AND the text tower
+        fi = None
         if variants is None:
             variants = batch_variants(self.text_variant_generator, self.config.text_variant_count, texts) \
                 if self.config.use_text_variants else [[] for _ in texts]
@@ -537,6 +549,8 @@ class MultiModalDefenseDetector:
                 flat.append(texts[i])
                 flat.extend(variants[i])
             ft = clip.encode_tokens(clip.tokenize(flat), True, group=N + 1).view(len(ids), N + 1, -1)
+            if fi is None:
+                fi = join_fi()
             sel = fi if len(ids) == n else fi[torch.as_tensor(ids, device=fi.device)].contiguous()
             rec = unpack_records(eng.detect_embeddings(sel, ft, self._cons_cfg(), use_bank, robust=True,
                                                        bank=self.bank_name), N)

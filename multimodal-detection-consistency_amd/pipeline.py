@@ -144,8 +144,16 @@ class MultiModalDetectionPipeline:
         results = [PipelineResult(original_text=t, pipeline_steps=list(steps)) for t in texts]
         dc = self.config.detector_config
         methods = [m for m in dc.detection_methods if m != "sd_reference" or "sd_reference" in steps]
+        image_rows = None
         try:
             variants = None
+            # the image tower needs nothing of the text side: it is enqueued (on the model's side stream) BEFORE the host
+            # generates the text variants, so that the variant generator's time runs under it instead of in front of it
+            if "detection" in steps and self.detector is not None and self.detector._get_clip_model() is self.clip_model:
+                x, _ = self.clip_model._images_to_device(images if isinstance(images, torch.Tensor) else list(images))
+                if x.shape[0] != n:
+                    raise ValueError("number of images and texts differ")
+                image_rows = self.clip_model.encode_image_beside(x, True)
             if "text_augment" in steps:
                 t0 = time.time()
                 variants = batch_variants(self.text_augmenter, dc.num_text_variants, texts)
@@ -179,7 +187,7 @@ class MultiModalDetectionPipeline:
                 kept: Optional[Dict[str, torch.Tensor]] = {} if share else None
                 det = self.detector.batch_detect(images, list(texts), methods=methods,
                                                  variants=variants if "text_variants" in methods else [[] for _ in texts],
-                                                 reference_images=ref_images, keep_features=kept)
+                                                 reference_images=ref_images, keep_features=kept, image_rows=image_rows)
                 dt = (time.time() - t0) / max(n, 1)
                 if share:
                     t1 = time.time()
@@ -192,6 +200,8 @@ class MultiModalDetectionPipeline:
                     r.detection_time = dt
                 self._count("detection", n, dt * n)
         except Exception as e:
+            if image_rows is not None:
+                image_rows()                 # the current stream waits for the image tower before its input can be released
             if self.config.strict:
                 raise
             for r in results:

@@ -155,11 +155,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && DH <= 48) ? 4 : 1)    /* = FaC
     // head dims 4 (i & 3) .. + 3 of a [16 keys][16 dims] block
     const int tr_off = (4 * g + (r16 >> 2)) * C::VROW + ((r16 & 3) << 3);
 
-    f32x4_t o[QB][DV];
-    float m_run[QB], l_run[QB];
+    // Softmax bookkeeping per 16-query block (second session of round 4; the tile loop is bound by vector issue at head_dim
+    // 40: 0.47 clocks per score and SIMD against 0.22 of MFMA):
+    //  * the row sums come out of the matrix pipe -- one more "V^T tile" of ones per 32 keys gives sum_k P[k, q] in every
+    //    accumulator row (as attention.hip does), over the SAME bf16-rounded probabilities the numerator uses and over all
+    //    four lane groups' keys at once: 16 adds per block and tile and the two closing shuffles less;
+    //  * the reference maximum `m_run` is LAZY: it moves (and the running output / sum are rescaled) only when the true
+    //    maximum has grown by more than 2^8 in the exponent's units -- the probabilities are then at most 2^8 instead of
+    //    at most 1, which neither bf16 nor the fp32 accumulators notice, and the final o / l does not depend on the
+    //    reference.  After the first tiles of a row no rescale happens: the exp of alpha and DV * 4 + 1 multiplies per
+    //    block and tile are skipped by a wave-uniform branch.
+    f32x4_t o[QB][DV], osum[QB];
+    float m_run[QB];
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
-        m_run[u] = -INFINITY; l_run[u] = 0.f;
+        m_run[u] = -INFINITY;
+        osum[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int md = 0; md < DV; ++md) o[u][md] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
@@ -203,22 +215,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && DH <= 48) ? 4 : 1)    /* = FaC
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[u], mx);          // finite: every tile holds at least one key < Tk
-            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * scale_log2);
-            const float mns = m_new * scale_log2;
-            m_run[u] = m_new;
-            float psum = 0.f;
+            // a row's first tile: m_run = -inf, so the difference is +inf and the reference is set (alpha = 0 on zeros)
+            const bool move = (m_new - m_run[u]) * scale_log2 > 8.0f;
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {                       // wave-uniform; rare after a row's first tiles
+                const float m_use = move ? m_new : m_run[u];
+                const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_use) * scale_log2);      // 1 for the lanes that stay
+                m_run[u] = m_use;
+                osum[u] *= alpha;
+#pragma unroll
+                for (int md = 0; md < DV; ++md) o[u][md] *= alpha;
+            }
+            const float mns = m_run[u] * scale_log2;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[u][t][r] = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], scale_log2, -mns));
-                    psum += s[u][t][r];
-                }
-            l_run[u] = l_run[u] * alpha + psum;
-#pragma unroll
-            for (int md = 0; md < DV; ++md)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[u][md][r] *= alpha;
+                for (int r = 0; r < 4; ++r) s[u][t][r] = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], scale_log2, -mns));
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const f32x4_t p0 = s[u][2 * kk], p1 = s[u][2 * kk + 1];
@@ -242,6 +253,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && DH <= 48) ? 4 : 1)    /* = FaC
 #pragma unroll
                 for (int u = 0; u < QB; ++u) o[u][md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[u][kk], o[u][md], 0, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < QB; ++u) osum[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u][kk], osum[u], 0, 0, 0);
         }
     };
     if (C::NSETS == 1) {
@@ -252,12 +265,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && DH <= 48) ? 4 : 1)    /* = FaC
             if (kt + 1 < nkt) tile(kt + 1, kregB, vregB);
         }
     }
-    // ---- the lane groups hold disjoint keys of the same query: combine the row sums, normalise, store
+    // ---- every row of the ones tile holds the query's sum over ALL keys: normalise, store
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
-        float l = l_run[u];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = osum[u][0];
         const int q = q0 + u * 16 + r16;
         if (q < Tq) {
             const float inv = 1.0f / l;

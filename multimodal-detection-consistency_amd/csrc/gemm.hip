@@ -571,8 +571,13 @@ hipError_t launch_gemm_bf16(const GemmLaunch& L, hipStream_t stream) {
     const int ntiles = nIt * nJt;
     const bool deep = (int64_t)L.K * L.planes >= 256;      // >= 8 ring stages per tile
     // (the ring's deep LDS-DMA pipeline also beats the one-tile kernel's wait-per-K-tile loop on launches of fewer
-    // tiles than CUs, one tile per workgroup: TVC_GEMM_RING_MIN_TILES, default 64)
-    static const int ring_min = [] { const char* v = getenv("TVC_GEMM_RING_MIN_TILES"); return v ? atoi(v) : 64; }();
+    // tiles than CUs, one tile per workgroup: TVC_GEMM_RING_MIN_TILES, default 8 -- 64 until the latent-diffusion model's
+    // guidance halves went to two streams: a half's 16 x 16-level launches are 30-60 tiles, and 8 / 16 / 32 / 64 gave
+    // 17.2 / 17.1 / 17.15 / 16.85 images/s with the same bits, profiles/r04_sd_ring_min_tiles.log)
+    static const int ring_min_env = [] { const char* v = getenv("TVC_GEMM_RING_MIN_TILES"); return v ? atoi(v) : 8; }();
+    // launches that may split K over idle CUs (`splitk_small`: the input-gradient path at small batches) keep the old bound:
+    // below 64 tiles they split
+    const int ring_min = (L.splitk_small && ring_min_env < 64) ? 64 : ring_min_env;
     // Launches that opted into split-K (`splitk_small`: the latent-diffusion model, whose results carry no batch-position
     // invariance to protect) and have 64..128 tiles of a DEEP K (a 3 x 3 convolution at 16 x 16 latents: 120 tiles x 180
     // K-tiles) also take the split-K kernels below instead of one tile per workgroup on half the chip.

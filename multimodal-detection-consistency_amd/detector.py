@@ -15,6 +15,7 @@ host: the stateful adaptive threshold / confidence of ``ConsistencyChecker``.
 from __future__ import annotations
 
 import logging
+import math
 import threading
 import time
 from dataclasses import dataclass, field
@@ -404,22 +405,52 @@ class ConsistencyChecker:
             return ws / tw if tw != 0 else 0.0
         raise ValueError(f"unknown voting strategy: {self.voting_strategy}")
 
+    # The three helpers below are plain-Python restatements of the reference's numpy expressions (np.mean / np.std /
+    # np.clip on 2-10 element lists) with numpy's own summation order, so the decisions stay bit-for-bit the reference's
+    # (tests/test_oracle_golden.py) at a tenth of the host time: 512 decisions cost 66 ms through numpy scalars.
+    @staticmethod
+    def _mean10(h: List[float]) -> float:
+        """np.mean of a list of up to 10 floats: numpy sums fewer than 8 elements left to right, 8 or more as eight
+        strided partial sums combined pairwise, then the tail left to right."""
+        n = len(h)
+        if n < 8:
+            t = 0.0
+            for x in h:
+                t += x
+            return t / n
+        t = ((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7]))
+        for x in h[8:]:
+            t += x
+        return t / n
+
     def _get_adaptive_threshold(self, s: Dict[str, float]) -> float:
         thr = self.base_threshold
         if s.get("cross_modal_variance", 0) > 0.1:
             thr += 0.1
-        if np.mean([s.get("text_variant_std", 0), s.get("retrieval_std", 0), s.get("generative_std", 0)]) > 0.2:
+        if (0.0 + s.get("text_variant_std", 0) + s.get("retrieval_std", 0) + s.get("generative_std", 0)) / 3 > 0.2:
             thr += 0.05
         if len(self.threshold_history) > 10:
-            thr = 0.7 * thr + 0.3 * np.mean(self.threshold_history[-10:])
-        return float(np.clip(thr, 0.1, 0.9))
+            thr = 0.7 * thr + 0.3 * self._mean10(self.threshold_history[-10:])
+        return float(min(max(thr, 0.1), 0.9)) if thr == thr else float(thr)
 
     def _compute_confidence(self, overall: float, thr: float, s: Dict[str, float]) -> float:
         dist = abs(overall - thr) / thr
         v = [s.get(n, 0) for n in self._NAMES if s.get(n, 0) > 0]
-        cons = 1.0 - np.std(v) if len(v) > 1 else 0.5
+        if len(v) > 1:
+            n = len(v)
+            t = 0.0
+            for x in v:
+                t += x
+            m = t / n
+            t = 0.0
+            for x in v:
+                t += (x - m) * (x - m)
+            cons = 1.0 - math.sqrt(t / n)
+        else:
+            cons = 0.5
         var = 1.0 - min(s.get("cross_modal_variance", 0), 1.0)
-        return float(np.clip(np.mean([dist, cons, var]), 0.0, 1.0))
+        c = (0.0 + dist + cons + var) / 3
+        return float(min(max(c, 0.0), 1.0)) if c == c else float(c)
 
     def make_decision(self, consistency_scores: Dict[str, float], return_details: bool = False) -> Dict[str, Any]:
         overall = self._compute_overall_score(consistency_scores)

@@ -103,6 +103,19 @@ class PGDAttacker:
             self._streams.append(torch.cuda.Stream(self.device))
         return self._pool[:n], self._streams[:n]
 
+    def close(self) -> None:
+        """Release the extra engine handles of `concurrent_batches` (the model's own engine is the model's to close)."""
+        for e in getattr(self, "_pool", [])[1:]:
+            e.close()
+        if hasattr(self, "_pool"):
+            self._pool = self._pool[:1]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _steps_concurrent(self, jobs: Sequence[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]) -> List[torch.Tensor]:
         """`_steps` for several batches at once, batch j on stream j / engine j; the random starts are drawn in batch
         order, so the outputs equal the sequential ones bit for bit."""

@@ -14,9 +14,14 @@
 //           max / count in registers and append the few survivors (v > tau) to
 //           a per-(chunk, query) list: slot from an LDS counter, no global
 //           atomics.
-//   pass 2  `bank_select_kernel`: one workgroup per query gathers its lists
-//           (~1-2k entries) into LDS and extracts the k best, ordered by
-//           (similarity desc, index asc); reduces the moments over chunks.
+//   pass 2  `bank_select_kernel`: one workgroup (1 024 threads) per query gathers its lists
+//           (~0.3-2k entries) into LDS, re-scores them exactly in the fast form and extracts the k
+//           best, ordered by (similarity desc, index asc); reduces the moments over chunks.
+//
+//   small query batches (M <= 64, the reference's own call pattern): pass 1 is `bank_filter_skinny_kernel` (the bank
+//           streamed once from HBM into MFMA operand registers) and, over a bf16 bank, pass 0 is
+//           `bank_sample_skinny_kernel` + `kth_groups_kernel` (the sample's 256 group maxima straight from the matrix
+//           pipe: no [M, n_sample] similarities).
 //
 //   fast form (no moments requested): pass 1 multiplies ONE product (bank hi x query hi) and
 //           filters against tau - margin[q], margin = a Cauchy-Schwarz bound of the dropped

@@ -22,6 +22,13 @@
 // 365-400 us against 277-292 us per ViT-L/14 layer call -- its 72 staging registers leave room for 0-4 pinned K tiles instead
 // of 15 and the block loop becomes LDS-bound.
 //
+// A persistent LDS-DMA stream (round 4, second session; git show 47e248b:multimodal-detection-consistency_amd/csrc/attention.hip has the
+// bit-identical form, EXPERIMENTS.md the four cuts): one 8-wave workgroup per CU walks 32 items, item i + 1's K / V images are
+// requested by global_load_lds_dwordx4 into the other half of the LDS (no staging registers) under item i's query blocks.
+// 269-282 us against 281-288 us at best, the step unchanged -- and with the fill fully hidden, the 17th block's query split
+// over the waves and no compiler-inserted wait left, still 279-293 us: the kernel is bound by the vector and matrix work of
+// its 17 query blocks (~2 700 VALU clocks each, 40 % of them the quarter-rate exp), not by the fill.  Not kept.
+//
 // A start stagger (round 4, second session: of the first two workgroups of a compute unit, the one in wave slot 1 sleeps
 // 6 400 / 12 800 / 19 200 / 25 600 clocks before its fill, so that one workgroup fills while the other multiplies;
 // scripts/attn_stagger_ab.sh, profiles/r04_attention_stagger_ab.log): 292-293 -> 283-286 us whatever the delay, -2.5 %:
@@ -33,7 +40,6 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
-#include <cstdlib>
 #include <mutex>
 
 #define ATT_DH 64
@@ -339,212 +345,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const uint16
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The ViT-L/14 vision case (257 tokens, every query, non-causal) as a PERSISTENT stream with LDS-DMA fills (round 4, second
-// session).  One workgroup of 8 waves per compute unit walks a contiguous range of (sequence, head) items; the K and V
-// images of item i + 1 are requested by `global_load_lds_dwordx4` -- no staging registers: the first persistent form lost
-// its pinned K tiles to 72 of them -- into the OTHER half of the LDS at the top of item i, and nobody waits for them until
-// the top of item i + 1: the fill of an item runs under the query blocks of the previous one instead of in front of its
-// own (the one-item kernel above: 10 k of a workgroup's 33 k clocks).
-//   * LDS: 2 x (K image + V image), 272 rows x 128 B each (139 KB).  The DMA writes 1 KiB per instruction, lane-linear, so
-//     both images have 128-byte rows and the XOR swizzle (16-byte position = chunk ^ ((row >> 1) & 7)) sits on the SOURCE
-//     address.  The same swizzle makes the transposed V reads conflict-free (ds_read_b64_tr_b16: 16 rows x two chunks per
-//     instruction land on 32 distinct 16-byte slots, every bank twice = the minimum), so V needs no 160-byte rows.
-//     Rows >= T re-read row T - 1 (their scores are masked by the -inf initialisation, their probabilities are 0).
-//   * a wave owns query blocks wave, wave + 8 (, 16): the Q fragments of item i + 1 are loaded into a block's registers
-//     right after that block's Q.K^T products of item i -- younger than the DMA, and first used after the next item's
-//     barrier -- so no compiler-counted wait for a load ever stands between a DMA and the barrier that publishes it.
-//   * one counted wait + one raw barrier per item; the arithmetic of a query block is the one-item kernel's, instruction
-//     for instruction: bit-identical outputs (tests/test_gpu_kernels.py) -- which the towers' batch-size invariance needs,
-//     because batches of fewer than 32 images keep the one-item kernel.
-// Measured (scripts/attn_stream_ab.sh, profiles/r04_attention_stream_ab.log; 512 x 16 heads x 257 tokens, same box): 269-282 us
-// against 281-288 us, attention 7.7 -> 7.4 ms per step, the step itself unchanged (98.1 ms).  The first cut was SLOWER
-// (304-313 us): hipcc's own wait for the Q fragments, placed behind the asm DMA it cannot count, was a vmcnt(0) that waited
-// the fill out in front of every item's first block; the fill is hidden now, and what is left is the chain of THREE query
-// blocks on the wave that owns block 16 (17 blocks over 8 waves; with the 10 instead of 15 pinned K tiles that the three Q
-// sets leave room for, an item takes 8.6 us where 2.1 block times would be 5-6).  Splitting block 16's one query over the
-// waves by key tiles would sum in another order than the one-item kernel and is therefore not done.
-// ---------------------------------------------------------------------------------------------------------------
-#define AVS_ROWS 272
-#define AVS_IMG (AVS_ROWS * 128)
-#define AVS_BUF (2 * AVS_IMG)
-__global__ __launch_bounds__(512) void attention_vit_stream_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                                   int T, int heads, int n_items, int ipw) {
-    constexpr int MAXT = 17;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int width = heads * ATT_DH;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int item_lo = wg * ipw;
-    int item_hi = item_lo + ipw;
-    if (item_hi > n_items) item_hi = n_items;
-    if (item_lo >= item_hi) return;
-    const int64_t ld = 3 * (int64_t)width;
-    const int g = lane >> 4, r16 = lane & 15;
-    const uint32_t smem_lds = lds_addr(smem);
-
-    // ---- LDS-DMA: piece j (8 rows x 128 B) of an image; lane = (row within the piece, 16-byte position)
-    const int drow = lane >> 3, dpos = lane & 7;
-    auto issue_fill = [&](int item, int buf, int first, int step) __attribute__((always_inline)) {
-        const int seq = item / heads, h = item - seq * heads;
-        const uint64_t kb64 = (uint64_t)(qkv + (int64_t)seq * T * ld + width + h * ATT_DH);
-        // (the bases are wave-uniform; through readfirstlane hipcc also knows it and keeps them in SGPRs for the asm)
-        const char* kbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kb64 >> 32)) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kb64));
-        const char* vbase = kbase + (int64_t)width * 2;
-        for (int j = first; j < AVS_ROWS / 8; j += step) {
-            const int key = 8 * j + drow;
-            const int kc = key < T ? key : T - 1;
-            const int c = dpos ^ ((key >> 1) & 7);
-            const uint32_t voff = (uint32_t)kc * (uint32_t)(ld * 2) + (uint32_t)c * 16u;
-            const uint32_t dst = smem_lds + (uint32_t)buf * AVS_BUF + (uint32_t)j * 1024u;
-            glds16_asm(kbase, voff, dst);
-            glds16_asm(vbase, voff, dst + AVS_IMG);
-        }
-    };
-    auto q_ptr = [&](int item, int qb) {
-        const int seq = item / heads, h = item - seq * heads;
-        int qrow = qb * 16 + r16;
-        qrow = qrow < T ? qrow : T - 1;
-        return qkv + ((int64_t)seq * T + qrow) * ld + h * ATT_DH + 8 * g;
-    };
-
-    // fragment read offsets (K as in the one-item kernel; V: the swizzled 128-byte rows)
-    const int sw0 = ((0 + g) ^ ((lane >> 1) & 7)) << 4;
-    const int sw1 = ((4 + g) ^ ((lane >> 1) & 7)) << 4;
-    const int vrow = 4 * g + (r16 >> 2);                    // key row within a 16-key tile
-    const int vf = (vrow >> 1) & 7;
-    int v_off[4];
-#pragma unroll
-    for (int md = 0; md < 4; ++md) v_off[md] = vrow * 128 + (((md * 2 + ((r16 & 3) >> 1)) ^ vf) << 4) + ((r16 & 1) << 3);
-    const float scale_log2 = 0.125f * 1.4426950408889634f;
-    f32x4_t pen_tail;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pen_tail[r] = ((MAXT - 1) * 16 + 4 * g + r >= T) ? -INFINITY : 0.f;
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
-
-    // ---- prologue: the first item's images and Q fragments
-    issue_fill(item_lo, 0, wave, 8);
-    bf16x8_t q0[3], q1[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        const int qb = wave + 8 * b;
-        q0[b] = bf16x8_t{}; q1[b] = bf16x8_t{};
-        if (qb < MAXT) { const uint16_t* qp = q_ptr(item_lo, qb); q0[b] = ATT_LD_Q((const bf16x8_t*)qp); q1[b] = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
-    }
-
-#ifndef AVS_KPIN
-#define AVS_KPIN 10       // pinned K tiles: 10 fit beside the three Q sets without a spill (11: 6 spilled registers, 12: 19, 14: 28)
-#endif
-    constexpr int KPIN = AVS_KPIN;
-    for (int item = item_lo; item < item_hi; ++item) {
-        const int buf = (item - item_lo) & 1;
-        // this item's images (DMA) and Q fragments have landed -- but NOT the two stores of the previous item's last block,
-        // the youngest entries of the in-order counter: waiting them out cost ~1 us per item on the wave with three blocks
-        if (item == item_lo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // ... of every wave; and every wave has left the other buffer
-        asm volatile("" ::: "memory");                         // (a raw barrier: __syncthreads() would drain the stores again)
-        const bool more = item + 1 < item_hi;
-        const char* ldsK = smem + buf * AVS_BUF;
-        const char* ldsV = ldsK + AVS_IMG;
-        const int seq = item / heads, h = item - seq * heads;
-        bf16x8_t ka[KPIN], kb[KPIN];
-#pragma unroll
-        for (int t = 0; t < KPIN; ++t) {
-            ka[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw0);
-            kb[t] = *(const bf16x8_t*)(ldsK + (t * 16 + r16) * ATT_KROW + sw1);
-        }
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int qb = wave + 8 * b;
-            if (qb >= MAXT) break;
-            const int qr = qb * 16 + r16;
-            int zoff = 0;
-            asm volatile("" : "+v"(zoff));          // opaque 0: keeps the un-pinned K reads inside the loop
-            const char* ldsK_i = ldsK + zoff;
-            f32x4_t s[MAXT];
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const f32x4_t c0 = (t == MAXT - 1) ? pen_tail : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                const bf16x8_t a0 = t < KPIN ? ka[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, q0[b], c0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const bf16x8_t a1 = t < KPIN ? kb[t < KPIN ? t : 0] : *(const bf16x8_t*)(ldsK_i + (t * 16 + r16) * ATT_KROW + sw1);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, q1[b], s[t], 0, 0, 0);
-            }
-            // this block's Q registers are free: the NEXT item's fragments for the same block (younger than the DMA above,
-            // first used after the next item's barrier)
-            if (more) { const uint16_t* qp = q_ptr(item + 1, qb); q0[b] = ATT_LD_Q((const bf16x8_t*)qp); q1[b] = ATT_LD_Q((const bf16x8_t*)(qp + 32)); }
-            // The NEXT item's images: requested by waves 1 .. 7 behind the Q loads of their LAST block.  hipcc does not count
-            // the asm loads, so a wait it places for one of its own loads behind them waits them out as well (first cut: a
-            // vmcnt(0) in front of the first block of every item): placed here, no compiler-visible load is waited for between
-            // the DMA and the next item's barrier.  Wave 0 has a third block and carries no piece.
-            if (more && wave != 0 && qb + 8 >= MAXT) issue_fill(item + 1, buf ^ 1, wave - 1, 7);
-            float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                m0 = __builtin_elementwise_maximum(m0, __builtin_elementwise_maximum(s[t][0], s[t][1]));
-                m1 = __builtin_elementwise_maximum(m1, __builtin_elementwise_maximum(s[t][2], s[t][3]));
-            }
-            float mx = __builtin_elementwise_maximum(m0, m1);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mxs = mx * scale_log2;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2, -mxs));
-            f32x4_t osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            f32x4_t o[4];
-#pragma unroll
-            for (int md = 0; md < 4; ++md) o[md] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < (MAXT + 1) / 2; ++u) {
-                const int t0 = 2 * u, t1 = 2 * u + 1;
-                const f32x4_t p0 = s[t0];
-                const f32x4_t p1 = (t1 < MAXT) ? s[t1 < MAXT ? t1 : 0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                u32x4_t pk;
-                pk[0] = pack_bf16x2(p0[0], p0[1]);
-                pk[1] = pack_bf16x2(p0[2], p0[3]);
-                pk[2] = pack_bf16x2(p1[0], p1[1]);
-                pk[3] = pack_bf16x2(p1[2], p1[3]);
-                const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pk);
-#pragma unroll
-                for (int md = 0; md < 4; ++md) {
-                    const char* vb = ldsV + v_off[md];
-                    const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vb + t0 * 16 * 128));
-                    const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vb + (t1 >= MAXT ? t0 : t1) * 16 * 128));
-                    bf16x8_t a;
-                    a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3];
-                    a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
-                    o[md] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, o[md], 0, 0, 0);
-                }
-                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, osum, 0, 0, 0);
-            }
-            const float inv = 1.0f / osum[0];
-            u32x4_t ow[2];
-#pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {
-                const f32x4_t v0 = o[2 * mp] * inv, v1 = o[2 * mp + 1] * inv;
-                const auto r0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-                ow[mp][0] = r0[0]; ow[mp][1] = r1[0]; ow[mp][2] = r0[1]; ow[mp][3] = r1[1];
-            }
-            if (qr < T) {
-                uint16_t* op = out + ((int64_t)seq * T + qr) * (int64_t)width + h * ATT_DH + (g & 1) * 16 + (g >> 1) * 8;
-                ATT_ST_O((u32x4_t*)op, ow[0]);
-                ATT_ST_O((u32x4_t*)(op + 32), ow[1]);
-            }
-        }
-    }
-}
-
 template <int MAXT, bool CAUSAL, int WPS, bool EXACT = false, int NW = 4>
 static hipError_t launch_one(const uint16_t* qkv, uint16_t* out, const int32_t* starts, int n_seq, int T,
                              int max_T, int heads, hipStream_t stream, const int32_t* pfx = nullptr,
@@ -586,23 +386,6 @@ hipError_t launch_attention(const uint16_t* qkv, uint16_t* out, const int32_t* s
         if (NT <= 2) return launch_one<2, true, 1>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
         if (NT <= 6) return launch_one<6, true, 2>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
         return launch_one<18, true, 4>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, pfx, pool_mode, pool_row);
-    }
-    if (!starts && NT == 17 && pool_mode == 0) {
-        // the persistent LDS-DMA stream (TVC_ATT_STREAM=0: the one-item kernel, for A/B runs); one workgroup per CU
-        static const bool stream_on = [] { const char* v = getenv("TVC_ATT_STREAM"); return !v || atoi(v) != 0; }();
-        const int64_t n_items = (int64_t)n_seq * heads;
-        if (stream_on && n_items >= 512 && n_items < (1 << 30) && (int64_t)seq_len * 3 * heads * ATT_DH * 2 * AVS_ROWS < (int64_t)1 << 32) {
-            static std::once_flag attr_once;
-            static hipError_t attr_st = hipSuccess;
-            std::call_once(attr_once, [] {
-                attr_st = hipFuncSetAttribute((const void*)attention_vit_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AVS_BUF);
-            });
-            if (attr_st != hipSuccess) return attr_st;
-            const int nwg = 256;
-            const int ipw = (int)((n_items + nwg - 1) / nwg);
-            hipLaunchKernelGGL(attention_vit_stream_kernel, dim3(nwg), dim3(512), 2 * AVS_BUF, stream, qkv, out, seq_len, heads, (int)n_items, ipw);
-            return hipGetLastError();
-        }
     }
     if (!starts && NT == 17) return launch_one<17, false, 4, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);   // ViT-L/14: 257 tokens
     if (!starts && NT == 4) return launch_one<4, false, 2, true>(qkv, out, starts, n_seq, seq_len, seq_len, heads, stream, nullptr, pool_mode, pool_row);     // ViT-B/32: 50 tokens

@@ -112,8 +112,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
     gemm_acc_t acc;
     gemm_zero_acc(acc);
     bf16x8_t a[8], b[4];
-    int credit = 0;              // upcoming waits that still see a fast epilogue's stores in the queue
-    const bool st16 = (EPI == TVC_EPI_BF16 || EPI == TVC_EPI_GELU_BF16) && (e.ldo & 7) == 0;
     int ct = 0, cks = 0;         // tile / k-stage of the stage the MFMAs of this wave work on
 
     auto tile_origin = [&](int t, int& i0, int& j0) {
@@ -138,26 +136,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_ring_kernel(GemmOperands g,
         __builtin_amdgcn_s_setprio(0);
     };
     // after the MFMAs of stage (ct, cks): tile epilogue when it was the tile's last stage
-    auto finish_stage = [&](int credit_after) {
+    auto finish_stage = [&](int) {
         if (++cks == nk) {
             int i0, j0;
             tile_origin(ct, i0, j0);
             gemm_tile_epilogue<EPI, true>(acc, g, e, i0, j0, wm, wn, lane, smem + RING_LDS_BYTES + (ct & 1) * 1024);
             gemm_zero_acc(acc);
-            const bool fast = (i0 + GEMM_BM <= g.I) && (j0 + GEMM_BN <= g.J) && ((e.ldo & 3) == 0);
-            credit = fast ? credit_after : 0;
             cks = 0; ++ct;
         }
     };
     auto retire_and_barrier = [&](int S) {
         const int n_out = (S + 3 < total ? S + 3 : total - 1) - S;           // stages in flight beyond S
-        // a fast epilogue left 32 (16 for the 16-byte bf16 form) stores in the queue behind the loads
-        if (n_out >= 3 && credit > 0 && st16) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-        else if (n_out >= 3 && credit > 0) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
-        else if (n_out >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        // (Rounds 1-3 credited a fast epilogue's 16 / 32 stores here -- vmcnt(24) / vmcnt(40) -- so that the waits behind a
+        // tile end did not drain them.  That assumed the counter retires in issue order; it does not between loads and stores
+        // (round 4: a vmcnt(2) meant to leave two stores in flight let OLDER loads arrive late in an attention experiment):
+        // stores that retire early would have let the wait pass with the stage's loads still in flight.  It never failed
+        // -- the loads were a whole epilogue old -- but this kernel is the any-shape fallback: correct by construction first.)
+        if (n_out >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (n_out == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (credit > 0) --credit;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };

@@ -838,10 +838,16 @@ def main():
                                                                 filter_low_quality=False, enable_cache=False), sd_model=sd, clip_model=clip))
         d_full, res_full = timed(lambda: det.batch_detect(images[:4], texts_sd), 2, 1)
         assert len(res_full) == 4 and all("sd_reference" in r["detection_scores"] for r in res_full)
+        # the same detector on 16 queries per call (48 generated references: the low-resolution UNet levels fill the chip)
+        nq16 = min(16, B)
+        texts_sd16, _ = make_captions(nq16, seed=5)
+        d_full16, res16 = timed(lambda: det.batch_detect(images[:nq16], texts_sd16), 1, 1)
+        assert len(res16) == nq16
         out["sd_reference"] = {"model": f"{sd.arch.name} geometry ({'v' if sd.arch.prediction_type == 'v_prediction' else 'epsilon'}-prediction, "
                                         f"heads {[sd.arch.heads_at(i) for i in range(len(sd.arch.block_out_channels))]}, cross-attention {sd.arch.cross_attention_dim}), random init",
                                "images_per_s": round(n_img * 2 / d_sd, 3), "images": n_img, "steps": steps_sd, "latent": "64x64",
                                "full_defense_qps": round(4 * 2 / d_full, 3),
+                               "full_defense_qps_16_queries_per_call": round(nq16 / d_full16, 3),
                                "full_defense_note": "AdversarialDetector.batch_detect with all three methods (text_variants + sd_reference + "
                                                     "consistency), 4 queries x 3 references x 20 steps per batch (BASELINE configs[4])",
                                "seconds_per_batch": round(d_sd / 2, 3),

@@ -86,7 +86,10 @@ struct Run {
     // filled the chip for a single image (S = 4 .. 16 at the 16 x 16 level) cost the 12-image batch 20 % of its GEMM time
     // (r04_bench1: 602 against 497 ms) -- throughput of the batched generator is what configs[4] measures; one image alone
     // runs its low-resolution levels on fewer workgroups than CUs.
-    static constexpr int NOMINAL_SAMPLES = 24;
+#ifndef TVC_SD_NOMINAL
+#define TVC_SD_NOMINAL 24
+#endif
+    static constexpr int NOMINAL_SAMPLES = TVC_SD_NOMINAL;
     static int fixed_split(int I, int K, int planes, int64_t rows_per_sample) {
         const int64_t tiles0 = (int64_t)((I + 255) / 256) * ((NOMINAL_SAMPLES * rows_per_sample + 255) / 256);
         const int nk64 = (int)((int64_t)K * planes / 64);
